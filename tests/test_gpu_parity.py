@@ -1,0 +1,230 @@
+"""GPU parity: every stage of the bootstrapped path, called through the C ABI
+(libtfhe_hip.so), against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact int32 results.  The oracle runs in exact-integer mode, i.e. it
+returns what the reference's f64 FFT returns whenever that FFT's error is below
+0.5 (measured margin on these inputs: ~0.015, see test_oracle_kat.py).
+"""
+import numpy as np
+import pytest
+
+import _oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = {"l2": (2, 10), "l3": (3, 7)}
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import tfhe_amd
+    e = tfhe_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def _hip_params(P):
+    import tfhe_amd
+    return tfhe_amd.make_params(P.n, P.N, P.k, P.l, P.bg_bit, P.ks_t, P.ks_base_bit, P.n_ks)
+
+
+def _load(eng, P, K):
+    eng.load_keys(_hip_params(P), K["bk"], K["ks_a"], K["ks_b"], K.get("ks_var"))
+
+
+# ---- isolated polynomial product ------------------------------------------------
+
+@pytest.mark.parametrize("half_bg,B", [(512, 37), (64, 8), (512, 1), (512, 2)])
+def test_polymul_full_and_accumulate(eng, half_bg, B):
+    d = orc.range_i32(100 + B, -half_bg, half_bg, (B, 1024))
+    s = orc.uniform_i32(200 + B, (B, 1024))
+    got = eng.polymul(d, s)
+    assert got.shape == (B, 2047)
+    for i in range(B):
+        want, _ = orc.poly_multiplier(d[i], s[i], orc.MUL_EXACT)
+        assert (got[i] == want).all(), i
+    r0 = orc.uniform_i32(300 + B, (B, 1024))
+    got = eng.polymul(d, s, accumulate_into=r0)
+    for i in range(B):
+        want, _ = orc.mul_r(r0[i], d[i], s[i], orc.MUL_EXACT)
+        assert (got[i] == want).all(), i
+
+
+def test_polymul_saturation_and_edges(eng):
+    B = 6
+    d = np.zeros((B, 1024), np.int32)
+    s = np.zeros((B, 1024), np.int32)
+    # exact coefficients straddling +-2^31 and +-(2^31 - 1)
+    d[0, 0], d[0, 1], s[0, 0], s[0, 1], s[0, 2] = 1, 1, 2**31 - 1, 1, 5
+    d[1, 0], d[1, 1], s[1, 0], s[1, 1], s[1, 2] = 1, 1, -2**31, -1, -5
+    d[2, 0], s[2, 0] = 1, 2**31 - 1
+    d[3, 0], s[3, 0] = -1, -2**31            # +2^31 saturates to 2^31-1
+    d[4, 1023], s[4, 1023] = -512, -2**31    # top coefficient of the 2047-long product
+    d[5, :] = -512
+    s[5, :] = 3                               # all-negative ramp, no saturation
+    got = eng.polymul(d, s)
+    for i in range(B):
+        want, _ = orc.poly_multiplier(d[i], s[i], orc.MUL_EXACT)
+        assert (got[i] == want).all(), i
+    # zeros in, zeros out (reference KAT /root/reference/src/numerics.rs:508-515)
+    z = eng.polymul(np.zeros((3, 1024), np.int32), np.zeros((3, 1024), np.int32))
+    assert z.shape == (3, 2047) and not z.any()
+
+
+# ---- external product, blind rotate -----------------------------------------------
+
+@pytest.mark.parametrize("tag", ["l2", "l3"])
+def test_extprod(eng, tag):
+    l, bg = SHAPES[tag]
+    P = orc.small_params(n=4, l=l, bg_bit=bg)
+    K = orc.generate_synthetic_keys(P, 7)
+    _load(eng, P, K)
+    B = 9
+    t = orc.uniform_i32(17, (B, 3, 1024))
+    t[0] = 0                      # digits of zero are not all zero (level >= 1 gives -Bg/2)
+    for idx in (0, 3):
+        got = eng.extprod(t, idx)
+        for b in range(B):
+            want, _, _ = orc.extern_mul(P, t[b], K["bk"][idx], None, orc.MUL_EXACT)
+            assert (got[b] == want).all(), (idx, b)
+
+
+@pytest.mark.parametrize("tag", ["l2", "l3"])
+def test_blind_rotate_hook(eng, tag):
+    l, bg = SHAPES[tag]
+    P = orc.small_params(n=7, l=l, bg_bit=bg)
+    K = orc.generate_synthetic_keys(P, 8)
+    _load(eng, P, K)
+    B = 5
+    acc = orc.uniform_i32(21, (B, 3, 1024))
+    bara = orc.range_i32(22, -1024, 1024, (B, P.n))
+    bara[0, :] = [1, -1, 0, 1023, -1024, -1023, 512]
+    bara[1, :] = 0                                   # every iteration skipped
+    got = eng.blind_rotate(acc, bara)
+    for b in range(B):
+        want, _, _ = orc.blind_rotate(P, acc[b], bara[b], K["bk"], None, orc.MUL_EXACT)
+        assert (got[b] == want).all(), b
+
+
+# ---- bootstrap, key switch, gates on non-degenerate keys ----------------------------
+
+@pytest.mark.parametrize("tag", ["l2", "l3"])
+def test_bootstrap_small_n(eng, tag):
+    l, bg = SHAPES[tag]
+    P = orc.small_params(n=8, l=l, bg_bit=bg)
+    K = orc.generate_synthetic_keys(P, 9)
+    _load(eng, P, K)
+    B = 6
+    a = orc.uniform_i32(31, (B, P.n))
+    b = orc.uniform_i32(32, (B,))
+    b[0], b[1] = -(1 << 20), -(1 << 20) - 1           # barb = 0 and barb = -1
+    mu = 1 << 29
+    ea, eb = eng.bootstrap_noks(mu, a, b)
+    oa, ob, var = eng.bootstrap(mu, a, b, want_var=True)
+    for i in range(B):
+        wa, wb, _ = orc.bootstrap_noks(P, K["bk"], mu, a[i], b[i], None, orc.MUL_EXACT)
+        assert (ea[i] == wa).all() and eb[i] == wb, i
+        wa, wb, wv, _ = orc.bootstrap(P, K["bk"], K["ks_a"], K["ks_b"], mu, a[i], b[i], None,
+                                      K["ks_var"], orc.MUL_EXACT)
+        assert (oa[i] == wa).all() and ob[i] == wb, i
+        assert var[i] == wv, i
+
+
+@pytest.mark.parametrize("n,n_ks", [(20, 20), (500, 500), (630, 630), (13, 1024)])
+def test_keyswitch(eng, n, n_ks):
+    P = orc.small_params(n=n)
+    P.n_ks = n_ks
+    P.l, P.bg_bit = 2, 10
+    K = orc.generate_synthetic_keys(P, 40 + n)
+    K["ks_a"][:, :, 0] = 0                            # the reference's h = 0 entries
+    K["ks_b"][:, :, 0] = 0
+    K["ks_var"][:, :, 0] = 0
+    # a tiny bootstrapping key: only the key-switch key matters here
+    eng.load_keys(_hip_params(P), K["bk"], K["ks_a"], K["ks_b"], K["ks_var"])
+    B = 5
+    a = orc.uniform_i32(51, (B, 1024))
+    a[0, :3] = [2**31 - 1, -2**31, (2**31 - 1) - (1 << 15)]   # aibar wraps
+    a[1, :] = 0
+    b = orc.uniform_i32(52, (B,))
+    oa, ob, var = eng.keyswitch(a, b, want_var=True)
+    for i in range(B):
+        wa, wb, wv = orc.key_switch(P, K["ks_a"], K["ks_b"], a[i], b[i], K["ks_var"])
+        assert (oa[i] == wa).all() and ob[i] == wb, i
+        assert var[i] == wv, i
+
+
+@pytest.mark.parametrize("tag", ["l2", "l3"])
+def test_gates_small_n(eng, tag):
+    l, bg = SHAPES[tag]
+    P = orc.small_params(n=6, l=l, bg_bit=bg)
+    K = orc.generate_synthetic_keys(P, 60)
+    _load(eng, P, K)
+    B = 3
+    ca = (orc.uniform_i32(61, (B, P.n)), orc.uniform_i32(62, (B,)))
+    cb = (orc.uniform_i32(63, (B, P.n)), orc.uniform_i32(64, (B,)))
+    cc = (orc.uniform_i32(65, (B, P.n)), orc.uniform_i32(66, (B,)))
+    for g in orc.GATES[:11]:
+        third = cc if g == "mux" else None
+        oa, ob, var = eng.gate(g, ca, cb, third, want_var=True)
+        for i in range(B):
+            sa = (ca[0][i], ca[1][i], 0.0)
+            sb = (cb[0][i], cb[1][i], 0.0)
+            sc = (cc[0][i], cc[1][i], 0.0)
+            wa, wb, wv = orc.gate(P, g, K, sa, sb, sc, orc.MUL_EXACT)
+            assert (oa[i] == wa).all() and ob[i] == wb, (g, i)
+            assert var[i] == wv, (g, i)
+
+
+# ---- full-size parameter sets -------------------------------------------------------
+
+@pytest.fixture(scope="module")
+def ref_keys80():
+    P = orc.params(80)
+    return P, orc.generate_keys(P, 0xC0FFEE)
+
+
+def test_nand_on_reference_style_keys(eng, ref_keys80):
+    """Keys generated the way the reference generates them: the external
+    product is identically zero, the result is the noiseless trivial sample
+    +-mu (sign of b + 2^20), and the decrypted bit must match the oracle's."""
+    P, K = ref_keys80
+    _load(eng, P, K)
+    B = 8
+    bits = [(i & 1, (i >> 1) & 1) for i in range(B)]
+    ca = [orc.encrypt(P, K["lwe_key"], x, 500 + i) for i, (x, _) in enumerate(bits)]
+    cb = [orc.encrypt(P, K["lwe_key"], y, 600 + i) for i, (_, y) in enumerate(bits)]
+    A = (np.stack([c[0] for c in ca]), np.array([c[1] for c in ca], np.int32))
+    Bm = (np.stack([c[0] for c in cb]), np.array([c[1] for c in cb], np.int32))
+    oa, ob, var = eng.gate("nand", A, Bm, want_var=True)
+    mu = 1 << 29
+    for i in range(B):
+        wa, wb, wv = orc.gate(P, "nand", K, ca[i], cb[i], None, orc.MUL_FFT)
+        assert (oa[i] == wa).all() and ob[i] == wb and var[i] == wv, i
+        assert not oa[i].any() and abs(int(ob[i])) == mu
+        assert orc.decrypt(oa[i], ob[i], K["lwe_key"]) == orc.decrypt(wa, wb, K["lwe_key"])
+
+
+@pytest.mark.parametrize("level,B", [(80, 2), (128, 1)])
+def test_bootstrap_full_size_synthetic_keys(eng, level, B):
+    P = orc.params(level)
+    K = orc.generate_synthetic_keys(P, 70 + level)
+    _load(eng, P, K)
+    a = orc.uniform_i32(71, (B, P.n))
+    b = orc.uniform_i32(72, (B,))
+    mu = 1 << 29
+    oa, ob, var = eng.bootstrap(mu, a, b, want_var=True)
+    for i in range(B):
+        wa, wb, wv, _ = orc.bootstrap(P, K["bk"], K["ks_a"], K["ks_b"], mu, a[i], b[i], None,
+                                      K["ks_var"], orc.MUL_EXACT)
+        assert (oa[i] == wa).all() and ob[i] == wb and var[i] == wv, i
+
+
+def test_errors_are_reported_not_thrown(eng):
+    import ctypes as C
+    import tfhe_amd
+    bad = tfhe_amd.make_params(8, N=512)
+    rc = eng.lib.tfhe_hip_load_keys(eng.ctx, C.byref(bad), None, None, None, None)
+    assert rc == -1
+    assert b"N=1024" in eng.lib.tfhe_hip_last_error(eng.ctx)
+    with pytest.raises(tfhe_amd.TfheHipError):
+        eng._check(rc)

@@ -1,0 +1,69 @@
+"""ctypes loader for libtfhe_hip.so (the C ABI declared in include/tfhe_hip.h).
+
+There is no fallback: if the shared library is missing or fails to load, the
+import raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``
+(or ``tfhe_amd.build.build_library()``).
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libtfhe_hip.so")
+
+SYMBOLS = [
+    "tfhe_hip_create", "tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_set_stream",
+    "tfhe_hip_synchronize", "tfhe_hip_load_keys", "tfhe_hip_key_blob_sizes",
+    "tfhe_hip_export_keys_dev", "tfhe_hip_import_keys_dev", "tfhe_hip_bootstrap",
+    "tfhe_hip_bootstrap_dev", "tfhe_hip_bootstrap_noks", "tfhe_hip_bootstrap_noks_dev",
+    "tfhe_hip_keyswitch", "tfhe_hip_keyswitch_dev", "tfhe_hip_gate", "tfhe_hip_gate_dev",
+    "tfhe_hip_polymul", "tfhe_hip_polymul_dev", "tfhe_hip_extprod", "tfhe_hip_blind_rotate",
+]
+
+
+class Params(C.Structure):
+    """tfhe_hip_params"""
+    _fields_ = [(f, C.c_int32) for f in
+                ("n", "N", "k", "l", "bg_bit", "ks_t", "ks_base_bit", "n_ks")]
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP library must be built (there is no CPU fallback)")
+    try:
+        # If torch is going to be used in this process it must own the HIP runtime.
+        import torch  # noqa: F401
+    except Exception:
+        pass
+    lib = C.CDLL(LIB_PATH)
+    vp, i32p, f64p, sz = C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t
+    PP = C.POINTER(Params)
+    lib.tfhe_hip_create.argtypes = [C.POINTER(vp), C.c_int]
+    lib.tfhe_hip_destroy.argtypes = [vp]
+    lib.tfhe_hip_destroy.restype = None
+    lib.tfhe_hip_last_error.argtypes = [vp]
+    lib.tfhe_hip_last_error.restype = C.c_char_p
+    lib.tfhe_hip_set_stream.argtypes = [vp, vp]
+    lib.tfhe_hip_synchronize.argtypes = [vp]
+    lib.tfhe_hip_load_keys.argtypes = [vp, PP, i32p, i32p, i32p, f64p]
+    lib.tfhe_hip_key_blob_sizes.argtypes = [PP, C.POINTER(sz), C.POINTER(sz)]
+    lib.tfhe_hip_export_keys_dev.argtypes = [vp, vp, vp]
+    lib.tfhe_hip_import_keys_dev.argtypes = [vp, PP, vp, vp]
+    for name in ("tfhe_hip_bootstrap", "tfhe_hip_bootstrap_dev"):
+        getattr(lib, name).argtypes = [vp, C.c_int32, i32p, i32p, i32p, i32p, f64p, sz]
+    for name in ("tfhe_hip_bootstrap_noks", "tfhe_hip_bootstrap_noks_dev"):
+        getattr(lib, name).argtypes = [vp, C.c_int32, i32p, i32p, i32p, i32p, sz]
+    for name in ("tfhe_hip_keyswitch", "tfhe_hip_keyswitch_dev"):
+        getattr(lib, name).argtypes = [vp, i32p, i32p, i32p, i32p, f64p, sz]
+    for name in ("tfhe_hip_gate", "tfhe_hip_gate_dev"):
+        getattr(lib, name).argtypes = [vp, C.c_int, i32p, i32p, i32p, i32p, i32p, i32p, i32p, i32p,
+                                       f64p, sz]
+    for name in ("tfhe_hip_polymul", "tfhe_hip_polymul_dev"):
+        getattr(lib, name).argtypes = [vp, i32p, i32p, i32p, C.c_int, sz]
+    lib.tfhe_hip_extprod.argtypes = [vp, i32p, C.c_int, i32p, sz]
+    lib.tfhe_hip_blind_rotate.argtypes = [vp, i32p, i32p, sz]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if name not in ("tfhe_hip_destroy", "tfhe_hip_last_error"):
+            fn.restype = C.c_int
+    return lib

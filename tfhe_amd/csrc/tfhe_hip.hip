@@ -1,0 +1,992 @@
+// tfhe_hip.hip — HIP kernels (gfx950) and the C ABI of libtfhe_hip.so.
+//
+// The bootstrapped-gate path of the reference crate, per ciphertext:
+//   gate prologue (src/gates.rs)            -> prologue_kernel
+//   mod switch, test vector, blind rotate,
+//   sample extract (src/bootstrapping.rs,
+//   src/tgsw.rs, src/tlwe.rs,
+//   src/numerics.rs, src/polynomial.rs)     -> blind_rotate_kernel
+//   key switch (src/lwe.rs:601-648)         -> keyswitch_kernel
+//
+// One wavefront owns one ciphertext for the whole blind rotation: its
+// accumulator lives in registers, every FFT exchange is wave-local (see
+// wave_fft.hpp), and the FFT-domain bootstrapping key is streamed from L2.
+// A workgroup is four independent wavefronts sharing two twiddle tables in LDS.
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/tfhe_hip.h"
+#include "wave_fft.hpp"
+
+using wfft::cplx;
+using wfft::static_for;
+
+namespace {
+
+constexpr int kN = 1024;
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = 64 * kWavesPerBlock;
+constexpr int kTableBytes = 2 * 1024 * (int)sizeof(cplx);                 // tE + twist
+constexpr int kLdsBytes = kWavesPerBlock * wfft::kWaveBytes + kTableBytes;  // 160 KiB
+
+__device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+__device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+__device__ __forceinline__ int32_t wneg(int32_t a) { return (int32_t)(0u - (uint32_t)a); }
+
+// decode_message(x, 2N), src/numerics.rs:126-130 with N = 1024.
+__device__ __forceinline__ int32_t mod_switch_2n(int32_t x) { return wadd(x, 1 << 20) >> 21; }
+
+// Copies the two twiddle tables (tE then twist, 1024 entries each) into LDS.
+__device__ __forceinline__ void load_tables(char* lds_tables, const cplx* __restrict__ tables) {
+  cplx* dst = reinterpret_cast<cplx*>(lds_tables);
+  for (int i = threadIdx.x; i < 2048; i += blockDim.x) dst[i] = tables[i];
+  __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// External product core (src/tgsw.rs:229-264, src/tlwe.rs:149-157,
+// src/numerics.rs:138-155).
+//
+// tt[j][r]: coefficient n = q + 32 r of polynomial j (j = 0..1) of the TLWE
+//           sample being decomposed, present in BOTH half-waves.
+// acc[r]  : lane (h, q) accumulates coefficient t = q + 32 r of result
+//           polynomial u = h.  Every product is rounded and saturated to i32
+//           on its own before the wrapping add, as the reference does.
+// bk      : FFT-domain key of this iteration, [l][2][32][64] cplx.
+// ---------------------------------------------------------------------------
+template <int L, int BGBIT>
+__device__ __forceinline__ void extprod_accumulate(const int32_t (&tt)[2][32], int32_t (&acc)[32],
+                                                   const cplx* __restrict__ bk, char* wave_tiles,
+                                                   const cplx* tE, const cplx* tw, int lane) {
+  const int h = lane >> 5, q = lane & 31;
+  constexpr int32_t kHalfBg = 1 << (BGBIT - 1);
+  constexpr int32_t kMask = (1 << BGBIT) - 1;
+  double re[32], im[32], hr[32], hi[32];
+#pragma unroll 1
+  for (int p = 0; p < L; p++) {
+    // gadget decomposition, src/tgsw.rs:299-328 (offset 0x80000000, tgsw.rs:50-52)
+    const int decal = 32 - (p + 1) * BGBIT;
+    static_for<0, 32>([&](auto ic) {
+      constexpr int r = decltype(ic)::value;
+      const int32_t b0 = wadd(tt[0][r], (int32_t)0x80000000u);
+      const int32_t b1 = wadd(tt[1][r], (int32_t)0x80000000u);
+      re[r] = (double)(((b0 >> decal) & kMask) - kHalfBg);
+      im[r] = (double)(((b1 >> decal) & kMask) - kHalfBg);
+    });
+    // C = FFT(d_{p,0} + i d_{p,1}); the two real spectra are separated with the mirror.
+    wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+    wfft::mirror2048(re, im, hr, hi, wave_tiles, q, h);
+    const cplx* b0 = bk + ((size_t)(p * 2 + 0) * 32) * 64 + lane;
+    const cplx* b1 = bk + ((size_t)(p * 2 + 1) * 32) * 64 + lane;
+    static_for<0, 32>([&](auto ic) {
+      constexpr int s = decltype(ic)::value;
+      const cplx k0 = b0[s * 64];
+      const cplx k1 = b1[s * 64];
+      // D0 = C + Ct, D1 = -i (C - Ct); the factor 1/2 is folded into the key.
+      const double d0r = re[s] + hr[s], d0i = im[s] + hi[s];
+      const double er = re[s] - hr[s], ei = im[s] - hi[s];
+      const double d1r = ei, d1i = -er;
+      re[s] = d0r * k0.x - d0i * k0.y;
+      im[s] = d0r * k0.y + d0i * k0.x;
+      hr[s] = d1r * k1.x - d1i * k1.y;
+      hi[s] = d1r * k1.y + d1i * k1.x;
+    });
+#pragma unroll 1
+    for (int j = 0; j < 2; j++) {
+      if (j == 1) {
+        static_for<0, 32>([&](auto ic) {
+          constexpr int s = decltype(ic)::value;
+          re[s] = hr[s];
+          im[s] = hi[s];
+        });
+      }
+      double out[32];
+      wfft::inv2048_first_half(re, im, out, wave_tiles, tE, tw, q, h);
+      static_for<0, 32>([&](auto ic) {
+        constexpr int r = decltype(ic)::value;
+        acc[r] = wadd(acc[r], wfft::round_sat_i32(out[r]));
+      });
+    }
+  }
+}
+
+// t = X^abar (prev + acc) - acc for polynomials 0 and 1
+// (src/bootstrapping.rs:136-146, src/polynomial.rs:281-313), staged through
+// the wavefront's LDS area.  acc/prev: split layout (lane (h,q) reg r = poly h,
+// coefficient q + 32 r).  tt: both polynomials in every lane.
+__device__ __forceinline__ void rotate_diff(const int32_t (&acc)[32], const int32_t (&prev)[32],
+                                            int32_t (&tt)[2][32], int abar, char* wave_tiles,
+                                            int lane) {
+  const int h = lane >> 5, q = lane & 31;
+  int32_t* S = reinterpret_cast<int32_t*>(wave_tiles);          // [2][1024] prev + acc
+  int32_t* A = S + 2 * kN;                                      // [2][1024] acc
+  wfft::wave_lds_fence();
+  static_for<0, 32>([&](auto ic) {
+    constexpr int r = decltype(ic)::value;
+    S[h * kN + q + 32 * r] = wadd(prev[r], acc[r]);
+    A[h * kN + q + 32 * r] = acc[r];
+  });
+  wfft::wave_lds_fence();
+  const bool all_neg = (abar == -kN);
+  static_for<0, 32>([&](auto ic) {
+    constexpr int r = decltype(ic)::value;
+    const int n = q + 32 * r;
+    const int src = (n - abar) & (kN - 1);
+    const bool neg = all_neg || (abar > 0 && n < abar);
+    static_for<0, 2>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      int32_t v = S[j * kN + src];
+      v = neg ? wneg(v) : v;
+      tt[j][r] = wsub(v, A[j * kN + n]);
+    });
+  });
+  wfft::wave_lds_fence();
+}
+
+struct BlindRotateArgs {
+  const int32_t* bara;      // [B][n]   mod-switched mask (src/bootstrapping.rs:51-55)
+  const int32_t* barb;      // [B]      mod-switched body (bootstrap mode)
+  const cplx* bkfft;        // [n][l][2][32][64]
+  const cplx* tables;       // tE[1024], twist[1024]
+  int32_t* acc_io;          // hook mode: [B][3][N] accumulators, updated in place
+  int32_t* out_a;           // bootstrap mode: [B][N] extracted mask
+  int32_t* out_b;           // bootstrap mode: [B]
+  int32_t mu;
+  int32_t n;
+  int32_t B;
+};
+
+// tfhe_blind_rotate_and_extract (src/bootstrapping.rs:77-134) when HOOK is
+// false; tfhe_blind_rotate on caller-supplied accumulators when HOOK is true.
+//
+// The accumulator's last polynomial (index k+1, where TLweSample::trivial puts
+// the test vector, src/tlwe.rs:99-109) is never decomposed and never written
+// by the external product (src/tgsw.rs:280-297, src/tlwe.rs:149-157), so it is
+// constant over the loop; only polynomials 0..k are carried.
+template <int L, int BGBIT, bool HOOK>
+__global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs args) {
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  char* lds_tables = lds + kWavesPerBlock * wfft::kWaveBytes;
+  load_tables(lds_tables, args.tables);
+  const cplx* tE = reinterpret_cast<const cplx*>(lds_tables);
+  const cplx* tw = tE + 1024;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, q = lane & 31;
+  const int b = blockIdx.x * kWavesPerBlock + wave;
+  if (b >= args.B) return;
+  char* wave_tiles = lds + wave * wfft::kWaveBytes;
+
+  int32_t acc[32], prev[32];
+  static_for<0, 32>([&](auto ic) {
+    constexpr int r = decltype(ic)::value;
+    prev[r] = 0;                                               // bootstrapping.rs:116-117
+    acc[r] = HOOK ? args.acc_io[((size_t)b * 3 + h) * kN + q + 32 * r] : 0;
+  });
+
+  const int32_t* bara = args.bara + (size_t)b * args.n;
+#pragma unroll 1
+  for (int i = 0; i < args.n; i++) {
+    const int abar = __builtin_amdgcn_readfirstlane(bara[i]);
+    if (abar == 0) continue;                                   // bootstrapping.rs:122-126
+    int32_t tt[2][32];
+    rotate_diff(acc, prev, tt, abar, wave_tiles, lane);
+    static_for<0, 32>([&](auto ic) {                           // prev <- acc; acc becomes acc + ext
+      constexpr int r = decltype(ic)::value;
+      prev[r] = acc[r];
+    });
+    extprod_accumulate<L, BGBIT>(tt, acc, args.bkfft + (size_t)i * L * 2 * 2048, wave_tiles, tE, tw,
+                                 lane);
+  }
+
+  if (HOOK) {
+    static_for<0, 32>([&](auto ic) {
+      constexpr int r = decltype(ic)::value;
+      args.acc_io[((size_t)b * 3 + h) * kN + q + 32 * r] = acc[r];
+    });
+  } else {
+    // extract_lwe, src/tlwe.rs:159-180 (k = 1): a[0] = acc0[0], a[j] = -acc0[N-j].
+    if (h == 0) {
+      int32_t* oa = args.out_a + (size_t)b * kN;
+      static_for<0, 32>([&](auto ic) {
+        constexpr int r = decltype(ic)::value;
+        const int t = q + 32 * r;
+        if (t == 0) oa[0] = acc[r];
+        else oa[kN - t] = wneg(acc[r]);
+      });
+    }
+    if (lane == 0) {
+      // b = coefficient 0 of X^{(-barb) mod 2N} * [mu]*N  (bootstrapping.rs:58-96,
+      // polynomial.rs:281-313): +mu iff barb >= 0.
+      const int32_t barb = args.barb[b];
+      args.out_b[b] = barb >= 0 ? args.mu : wneg(args.mu);
+    }
+  }
+}
+
+// tgsw_extern_mul_to_tlwe on caller-supplied samples (parity hook).
+template <int L, int BGBIT>
+__global__ __launch_bounds__(kBlock, 1) void extprod_kernel(const int32_t* __restrict__ t,
+                                                            const cplx* __restrict__ bk_i,
+                                                            const cplx* __restrict__ tables,
+                                                            int32_t* __restrict__ out, int B) {
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  char* lds_tables = lds + kWavesPerBlock * wfft::kWaveBytes;
+  load_tables(lds_tables, tables);
+  const cplx* tE = reinterpret_cast<const cplx*>(lds_tables);
+  const cplx* tw = tE + 1024;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, q = lane & 31;
+  const int b = blockIdx.x * kWavesPerBlock + wave;
+  if (b >= B) return;
+  char* wave_tiles = lds + wave * wfft::kWaveBytes;
+  int32_t tt[2][32], acc[32];
+  static_for<0, 32>([&](auto ic) {
+    constexpr int r = decltype(ic)::value;
+    tt[0][r] = t[((size_t)b * 3 + 0) * kN + q + 32 * r];
+    tt[1][r] = t[((size_t)b * 3 + 1) * kN + q + 32 * r];
+    acc[r] = 0;
+  });
+  extprod_accumulate<L, BGBIT>(tt, acc, bk_i, wave_tiles, tE, tw, lane);
+  static_for<0, 32>([&](auto ic) {
+    constexpr int r = decltype(ic)::value;
+    out[((size_t)b * 3 + h) * kN + q + 32 * r] = acc[r];
+    if (h == 0) out[((size_t)b * 3 + 2) * kN + q + 32 * r] = 0;     // tgsw.rs:236-244
+  });
+}
+
+// One-time transform of the bootstrapping key (replaces the per-call forward
+// FFT of the key polynomial at src/numerics.rs:216-238).  One wavefront per
+// (i, row, col): spectrum of a[0] + i a[1], scaled by 1/4096 (1/2048 for the
+// inverse transform, 1/2 for the real-spectrum separation).
+__global__ __launch_bounds__(kBlock, 1) void bk_fft_kernel(const int32_t* __restrict__ bk,
+                                                           const cplx* __restrict__ tables,
+                                                           cplx* __restrict__ bkfft, int count) {
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  char* lds_tables = lds + kWavesPerBlock * wfft::kWaveBytes;
+  load_tables(lds_tables, tables);
+  const cplx* tE = reinterpret_cast<const cplx*>(lds_tables);
+  const cplx* tw = tE + 1024;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, q = lane & 31;
+  const int s = blockIdx.x * kWavesPerBlock + wave;
+  if (s >= count) return;
+  char* wave_tiles = lds + wave * wfft::kWaveBytes;
+  const int32_t* p0 = bk + (size_t)s * 2 * kN;
+  double re[32], im[32];
+  static_for<0, 32>([&](auto ic) {
+    constexpr int r = decltype(ic)::value;
+    re[r] = (double)p0[q + 32 * r];
+    im[r] = (double)p0[kN + q + 32 * r];
+  });
+  wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+  cplx* dst = bkfft + (size_t)s * 2048 + lane;
+  static_for<0, 32>([&](auto ic) {
+    constexpr int p = decltype(ic)::value;
+    cplx v;
+    v.x = re[p] * (1.0 / 4096.0);
+    v.y = im[p] * (1.0 / 4096.0);
+    dst[p * 64] = v;
+  });
+}
+
+// poly_multiplier / torus_polynomial_mul_r on independent pairs.  One
+// wavefront multiplies two pairs: FFT(d_a + i d_b), FFT(s_a + i s_b), the four
+// real spectra are separated with the mirror, Z = D_a S_a + i D_b S_b, and one
+// inverse transform returns product a in the real part, product b in the
+// imaginary part.
+template <bool ACCUMULATE>
+__global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __restrict__ d,
+                                                            const int32_t* __restrict__ s,
+                                                            const cplx* __restrict__ tables,
+                                                            int32_t* __restrict__ out, int B) {
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  char* lds_tables = lds + kWavesPerBlock * wfft::kWaveBytes;
+  load_tables(lds_tables, tables);
+  const cplx* tE = reinterpret_cast<const cplx*>(lds_tables);
+  const cplx* tw = tE + 1024;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = lane >> 5, q = lane & 31;
+  const int pair = blockIdx.x * kWavesPerBlock + wave;
+  const int ia = 2 * pair, ib = 2 * pair + 1;
+  if (ia >= B) return;
+  const bool has_b = ib < B;
+  char* wave_tiles = lds + wave * wfft::kWaveBytes;
+
+  double re[32], im[32], mr[32], mi[32], dar[32], dai[32], dbr[32], dbi[32];
+  static_for<0, 32>([&](auto ic) {
+    constexpr int r = decltype(ic)::value;
+    re[r] = (double)d[(size_t)ia * kN + q + 32 * r];
+    im[r] = has_b ? (double)d[(size_t)ib * kN + q + 32 * r] : 0.0;
+  });
+  wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+  wfft::mirror2048(re, im, mr, mi, wave_tiles, q, h);
+  static_for<0, 32>([&](auto ic) {
+    constexpr int p = decltype(ic)::value;
+    dar[p] = re[p] + mr[p];            // 2 D_a
+    dai[p] = im[p] + mi[p];
+    dbr[p] = im[p] - mi[p];            // 2 D_b = -i (C - Ct)
+    dbi[p] = -(re[p] - mr[p]);
+  });
+  static_for<0, 32>([&](auto ic) {
+    constexpr int r = decltype(ic)::value;
+    re[r] = (double)s[(size_t)ia * kN + q + 32 * r];
+    im[r] = has_b ? (double)s[(size_t)ib * kN + q + 32 * r] : 0.0;
+  });
+  wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+  wfft::mirror2048(re, im, mr, mi, wave_tiles, q, h);
+  constexpr double kScale = 1.0 / (4.0 * 2048.0);
+  static_for<0, 32>([&](auto ic) {
+    constexpr int p = decltype(ic)::value;
+    const double sar = re[p] + mr[p], sai = im[p] + mi[p];
+    const double sbr = im[p] - mi[p], sbi = -(re[p] - mr[p]);
+    const double zar = dar[p] * sar - dai[p] * sai, zai = dar[p] * sai + dai[p] * sar;
+    const double zbr = dbr[p] * sbr - dbi[p] * sbi, zbi = dbr[p] * sbi + dbi[p] * sbr;
+    re[p] = (zar - zbi) * kScale;      // Z = Z_a + i Z_b
+    im[p] = (zai + zbr) * kScale;
+  });
+  // Inverse transform; the second half of the outputs (t >= N) is E - twist*O.
+  wfft::fft1024_inv(re, im, wave_tiles + h * wfft::kHalfBytes, tE, q);
+  wfft::twist_odd_half<true>(re, im, tw, q, h);
+  const int prod = h ? ib : ia;        // half E ends with product a, half O with product b
+  const bool live = h ? has_b : true;
+  static_for<0, 32>([&](auto ic) {
+    constexpr int r = decltype(ic)::value;
+    const int t = q + 32 * r;
+    const double send = h ? re[r] : im[r];
+    const double keep = h ? im[r] : re[r];
+    const double other = wfft::xchg32(send, h);
+    // half E: keep = Re E, other = Re(tw O); half O: keep = Im(tw O), other = Im E
+    const double lo = keep + other;
+    const double hi_ = h ? (other - keep) : (keep - other);
+    if (live) {
+      if (ACCUMULATE) {
+        int32_t* o = out + (size_t)prod * kN + t;
+        *o = wadd(*o, wfft::round_sat_i32(lo));
+      } else {
+        int32_t* o = out + (size_t)prod * (2 * kN - 1);
+        o[t] = wfft::round_sat_i32(lo);
+        if (t < kN - 1) o[kN + t] = wfft::round_sat_i32(hi_);
+      }
+    }
+  });
+}
+
+// Gate prologue + mod switch: x = C + wa*ca + wb*cb (wrapping, src/gates.rs,
+// src/lwe.rs:47-136), then bara/barb = decode_message(x, 2N)
+// (src/bootstrapping.rs:50-55).
+__global__ void prologue_kernel(const int32_t* __restrict__ ca_a, const int32_t* __restrict__ ca_b,
+                                const int32_t* __restrict__ cb_a, const int32_t* __restrict__ cb_b,
+                                int wa, int wb, int32_t c, int n, size_t total,
+                                int32_t* __restrict__ bara, int32_t* __restrict__ barb) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const size_t b = idx / (size_t)(n + 1);
+  const int i = (int)(idx - b * (size_t)(n + 1));
+  if (i < n) {
+    uint32_t x = (uint32_t)wa * (uint32_t)ca_a[b * n + i];
+    if (cb_a) x += (uint32_t)wb * (uint32_t)cb_a[b * n + i];
+    bara[b * n + i] = mod_switch_2n((int32_t)x);
+  } else {
+    uint32_t x = (uint32_t)c + (uint32_t)wa * (uint32_t)ca_b[b];
+    if (cb_b) x += (uint32_t)wb * (uint32_t)cb_b[b];
+    barb[b] = mod_switch_2n((int32_t)x);
+  }
+}
+
+// lwe_key_switch (src/lwe.rs:601-648).  One workgroup per ciphertext; thread v
+// owns four consecutive output coefficients (the body b is stored right after
+// the mask in each key row).  in2 (optional) and c_b implement the sum
+// trivial(c) + u1 + u2 of the mux gate (src/gates.rs:264-266).
+__global__ __launch_bounds__(256) void keyswitch_kernel(
+    const int32_t* __restrict__ in_a, const int32_t* __restrict__ in_b,
+    const int32_t* __restrict__ in2_a, const int32_t* __restrict__ in2_b, int32_t c_b,
+    int in_stride, const int32_t* __restrict__ ks_rows, const double* __restrict__ ks_var,
+    int row_stride, int n, int n_ks, int t, int32_t* __restrict__ out_a,
+    int32_t* __restrict__ out_b, double* __restrict__ var_out) {
+  const int b = blockIdx.x;
+  const int v = threadIdx.x;
+  const int nvec = row_stride / 4;
+  const int32_t* xa = in_a + (size_t)b * in_stride;
+  const int32_t* xa2 = in2_a ? in2_a + (size_t)b * in_stride : nullptr;
+  const int32_t prec_offset = 1 << (32 - (1 + 2 * t));
+  uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  if (v < nvec) {
+    for (int i = 0; i < n_ks; i++) {
+      int32_t ai = xa[i];
+      if (xa2) ai = wadd(ai, xa2[i]);
+      const int32_t aibar = wadd(ai, prec_offset);
+      for (int j = 0; j < t; j++) {
+        const int aij = (aibar >> (32 - (j + 1) * 2)) & 3;
+        if (aij != 0) {
+          const int4 row = *reinterpret_cast<const int4*>(
+              ks_rows + ((size_t)(i * t + j) * 4 + aij) * row_stride + 4 * v);
+          a0 -= (uint32_t)row.x; a1 -= (uint32_t)row.y; a2 -= (uint32_t)row.z; a3 -= (uint32_t)row.w;
+        }
+      }
+    }
+    uint32_t acc4[4] = {a0, a1, a2, a3};
+    for (int e = 0; e < 4; e++) {
+      const int x = 4 * v + e;
+      if (x < n) out_a[(size_t)b * n + x] = (int32_t)acc4[e];
+      else if (x == n) {
+        int32_t bb = in_b[b];
+        if (in2_b) bb = wadd(wadd(c_b, bb), in2_b[b]);
+        out_b[b] = wadd(bb, (int32_t)acc4[e]);
+      }
+    }
+  }
+  if (var_out && v == 0) {
+    double var = 0.0;       // summed in the reference's order, lwe.rs:109
+    for (int i = 0; i < n_ks; i++) {
+      int32_t ai = xa[i];
+      if (xa2) ai = wadd(ai, xa2[i]);
+      const int32_t aibar = wadd(ai, prec_offset);
+      for (int j = 0; j < t; j++) {
+        const int aij = (aibar >> (32 - (j + 1) * 2)) & 3;
+        if (aij != 0) var += ks_var[(size_t)(i * t + j) * 4 + aij];
+      }
+    }
+    var_out[b] = var;
+  }
+}
+
+// Packs the key-switch key into rows [a_0 .. a_{n-1}, b, 0 pad] of row_stride int32.
+__global__ void ks_pack_kernel(const int32_t* __restrict__ ks_a, const int32_t* __restrict__ ks_b,
+                               int n, int row_stride, size_t rows, int32_t* __restrict__ dst) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * (size_t)row_stride) return;
+  const size_t row = idx / row_stride;
+  const int x = (int)(idx - row * row_stride);
+  dst[idx] = x < n ? ks_a[row * n + x] : (x == n ? ks_b[row] : 0);
+}
+
+}  // namespace
+
+// ===========================================================================
+// Host side
+// ===========================================================================
+
+struct tfhe_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool have_keys = false;
+  tfhe_hip_params P{};
+  int row_stride = 0;
+  cplx* tables = nullptr;        // device: tE[1024], twist[1024]
+  cplx* bkfft = nullptr;         // device blob 1
+  char* ksblob = nullptr;        // device blob 2: rows then variances
+  size_t bk_bytes = 0, ks_bytes = 0, ks_rows_bytes = 0;
+  // scratch, grown on demand
+  void* scratch = nullptr;
+  size_t scratch_bytes = 0;
+};
+
+namespace {
+
+int fail(tfhe_hip_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                           \
+  do {                                                                               \
+    hipError_t e_ = (expr);                                                          \
+    if (e_ != hipSuccess)                                                            \
+      return fail(ctx, TFHE_HIP_ERR_RUNTIME,                                         \
+                  std::string(#expr) + ": " + hipGetErrorString(e_));                \
+  } while (0)
+
+int check_params(tfhe_hip_ctx* ctx, const tfhe_hip_params* p) {
+  if (!p) return fail(ctx, TFHE_HIP_ERR_ARG, "params is NULL");
+  if (p->N != kN || p->k != 1) return fail(ctx, TFHE_HIP_ERR_ARG, "only N=1024, k=1 is supported");
+  if (!((p->l == 2 && p->bg_bit == 10) || (p->l == 3 && p->bg_bit == 7)))
+    return fail(ctx, TFHE_HIP_ERR_ARG, "supported (l, bg_bit): (2, 10) and (3, 7)");
+  if (p->ks_base_bit != 2 || p->ks_t < 1 || p->ks_t * 2 > 31)
+    return fail(ctx, TFHE_HIP_ERR_ARG, "key switch: base_bit must be 2 and 1 <= t <= 15");
+  if (p->n < 1 || p->n > 1020 || p->n_ks < 1 || p->n_ks > p->N * p->k)
+    return fail(ctx, TFHE_HIP_ERR_ARG, "need 1 <= n <= 1020 and 1 <= n_ks <= N*k");
+  return 0;
+}
+
+int row_stride_of(const tfhe_hip_params* p) { return ((p->n + 1 + 3) / 4) * 4; }
+
+void blob_sizes(const tfhe_hip_params* p, size_t* bk, size_t* ks, size_t* ks_rows) {
+  *bk = (size_t)p->n * p->l * 2 * 2048 * sizeof(cplx);
+  size_t rows = (size_t)p->n_ks * p->ks_t * 4;
+  *ks_rows = rows * row_stride_of(p) * sizeof(int32_t);
+  *ks = *ks_rows + rows * sizeof(double);
+}
+
+int ensure_scratch(tfhe_hip_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->scratch_bytes) return 0;
+  if (ctx->scratch) HIP_TRY(ctx, hipFree(ctx->scratch));
+  ctx->scratch = nullptr;
+  ctx->scratch_bytes = 0;
+  HIP_TRY(ctx, hipMalloc(&ctx->scratch, bytes));
+  ctx->scratch_bytes = bytes;
+  return 0;
+}
+
+int alloc_keys(tfhe_hip_ctx* ctx, const tfhe_hip_params* p) {
+  if (ctx->bkfft) { HIP_TRY(ctx, hipFree(ctx->bkfft)); ctx->bkfft = nullptr; }
+  if (ctx->ksblob) { HIP_TRY(ctx, hipFree(ctx->ksblob)); ctx->ksblob = nullptr; }
+  ctx->have_keys = false;
+  ctx->P = *p;
+  ctx->row_stride = row_stride_of(p);
+  blob_sizes(p, &ctx->bk_bytes, &ctx->ks_bytes, &ctx->ks_rows_bytes);
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->bkfft, ctx->bk_bytes));
+  HIP_TRY(ctx, hipMalloc((void**)&ctx->ksblob, ctx->ks_bytes));
+  return 0;
+}
+
+template <class K>
+int set_big_lds(tfhe_hip_ctx* ctx, K kernel) {
+  (void)ctx; (void)kernel;
+  return 0;
+}
+
+struct Weights { int wa, wb; int32_t c, mu; };
+
+bool gate_weights(int gate, Weights* w) {
+  const int32_t e8 = 1 << 29, m8 = -(1 << 29), e4 = 1 << 30, m4 = (int32_t)0xC0000000u;
+  switch (gate) {                                            // src/gates.rs
+    case TFHE_HIP_NAND:  *w = {-1, -1, e8, e8}; return true;   // :23-41
+    case TFHE_HIP_OR:    *w = {+1, +1, e8, e8}; return true;   // :44-61
+    case TFHE_HIP_AND:   *w = {+1, +1, m8, e8}; return true;   // :64-80
+    case TFHE_HIP_XOR:   *w = {+2, +2, e4, e8}; return true;   // :83-99
+    case TFHE_HIP_XNOR:  *w = {-2, -2, m4, e8}; return true;   // :102-119
+    case TFHE_HIP_NOR:   *w = {-1, -1, m8, m8}; return true;   // :127-143
+    case TFHE_HIP_ANDNY: *w = {-1, +1, m8, e8}; return true;   // :147-162
+    case TFHE_HIP_ANDYN: *w = {+1, -1, m8, e8}; return true;   // :166-182
+    case TFHE_HIP_ORNY:  *w = {-1, +1, e8, e8}; return true;   // :186-202
+    case TFHE_HIP_ORYN:  *w = {+1, -1, e8, e8}; return true;   // :206-222
+    default: return false;
+  }
+}
+
+// scratch layout for a batch of B: bara [B][n], barb [B], ea [B][N], eb [B],
+// ea2 [B][N], eb2 [B]
+struct Scratch {
+  int32_t *bara, *barb, *ea, *eb, *ea2, *eb2;
+};
+
+int get_scratch(tfhe_hip_ctx* ctx, size_t B, bool two, Scratch* s) {
+  const size_t n = ctx->P.n;
+  auto up = [](size_t x) { return (x + 63) / 64 * 64; };
+  size_t o_bara = 0, o_barb = o_bara + up(B * n * 4), o_ea = o_barb + up(B * 4);
+  size_t o_eb = o_ea + up(B * kN * 4), o_ea2 = o_eb + up(B * 4);
+  size_t o_eb2 = o_ea2 + (two ? up(B * kN * 4) : 0), total = o_eb2 + (two ? up(B * 4) : 0);
+  if (int rc = ensure_scratch(ctx, total)) return rc;
+  char* base = (char*)ctx->scratch;
+  s->bara = (int32_t*)(base + o_bara); s->barb = (int32_t*)(base + o_barb);
+  s->ea = (int32_t*)(base + o_ea); s->eb = (int32_t*)(base + o_eb);
+  s->ea2 = two ? (int32_t*)(base + o_ea2) : nullptr; s->eb2 = two ? (int32_t*)(base + o_eb2) : nullptr;
+  return 0;
+}
+
+int launch_prologue(tfhe_hip_ctx* ctx, const int32_t* ca_a, const int32_t* ca_b, const int32_t* cb_a,
+                    const int32_t* cb_b, int wa, int wb, int32_t c, size_t B, int32_t* bara,
+                    int32_t* barb) {
+  const size_t total = B * (size_t)(ctx->P.n + 1);
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  hipLaunchKernelGGL(prologue_kernel, dim3(grid), dim3(256), 0, ctx->stream, ca_a, ca_b, cb_a, cb_b,
+                     wa, wb, c, ctx->P.n, total, bara, barb);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_blind_rotate(tfhe_hip_ctx* ctx, const int32_t* bara, const int32_t* barb, int32_t mu,
+                        int32_t* acc_io, int32_t* out_a, int32_t* out_b, size_t B) {
+  BlindRotateArgs a;
+  a.bara = bara; a.barb = barb; a.bkfft = ctx->bkfft; a.tables = ctx->tables;
+  a.acc_io = acc_io; a.out_a = out_a; a.out_b = out_b; a.mu = mu; a.n = ctx->P.n; a.B = (int32_t)B;
+  const unsigned grid = (unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock);
+  const bool hook = acc_io != nullptr;
+  if (ctx->P.l == 2) {
+    if (hook) hipLaunchKernelGGL((blind_rotate_kernel<2, 10, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((blind_rotate_kernel<2, 10, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+  } else {
+    if (hook) hipLaunchKernelGGL((blind_rotate_kernel<3, 7, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((blind_rotate_kernel<3, 7, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int launch_keyswitch(tfhe_hip_ctx* ctx, const int32_t* in_a, const int32_t* in_b, const int32_t* in2_a,
+                     const int32_t* in2_b, int32_t c_b, int32_t* out_a, int32_t* out_b,
+                     double* var_out, size_t B) {
+  const double* ks_var = (const double*)(ctx->ksblob + ctx->ks_rows_bytes);
+  hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)B), dim3(256), 0, ctx->stream, in_a, in_b, in2_a,
+                     in2_b, c_b, kN, (const int32_t*)ctx->ksblob, ks_var, ctx->row_stride, ctx->P.n,
+                     ctx->P.n_ks, ctx->P.ks_t, out_a, out_b, var_out);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+void make_tables(std::vector<cplx>& t) {
+  t.resize(2048);
+  const long double two_pi = 6.283185307179586476925286766559L;
+  for (int kb = 0; kb < 32; kb++)
+    for (int q = 0; q < 32; q++) {
+      long double ang = -two_pi * (long double)(q * kb) / 1024.0L;
+      t[kb * 32 + q].x = (double)cosl(ang);
+      t[kb * 32 + q].y = (double)sinl(ang);
+    }
+  for (int r = 0; r < 32; r++)
+    for (int q = 0; q < 32; q++) {
+      long double ang = -two_pi * (long double)(q + 32 * r) / 2048.0L;
+      t[1024 + r * 32 + q].x = (double)cosl(ang);
+      t[1024 + r * 32 + q].y = (double)sinl(ang);
+    }
+}
+
+int need_keys(tfhe_hip_ctx* ctx) {
+  if (!ctx) return TFHE_HIP_ERR_ARG;
+  if (!ctx->have_keys) return fail(ctx, TFHE_HIP_ERR_STATE, "no keys loaded");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return 0;
+}
+
+// Staging helpers for the host-pointer entry points.
+struct DevBuf {
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int tfhe_hip_create(tfhe_hip_ctx** out, int device) {
+  if (!out) return TFHE_HIP_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return TFHE_HIP_ERR_RUNTIME;
+  tfhe_hip_ctx* ctx = new tfhe_hip_ctx();
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete ctx; return TFHE_HIP_ERR_RUNTIME; }
+  std::vector<cplx> t;
+  make_tables(t);
+  if (hipMalloc((void**)&ctx->tables, t.size() * sizeof(cplx)) != hipSuccess ||
+      hipMemcpy(ctx->tables, t.data(), t.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) {
+    delete ctx;
+    return TFHE_HIP_ERR_RUNTIME;
+  }
+  *out = ctx;
+  return 0;
+}
+
+void tfhe_hip_destroy(tfhe_hip_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->tables) (void)hipFree(ctx->tables);
+  if (ctx->bkfft) (void)hipFree(ctx->bkfft);
+  if (ctx->ksblob) (void)hipFree(ctx->ksblob);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  delete ctx;
+}
+
+const char* tfhe_hip_last_error(tfhe_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int tfhe_hip_set_stream(tfhe_hip_ctx* ctx, void* hip_stream) {
+  if (!ctx) return TFHE_HIP_ERR_ARG;
+  ctx->stream = (hipStream_t)hip_stream;
+  return 0;
+}
+
+int tfhe_hip_synchronize(tfhe_hip_ctx* ctx) {
+  if (!ctx) return TFHE_HIP_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int tfhe_hip_key_blob_sizes(const tfhe_hip_params* params, size_t* bk_bytes, size_t* ks_bytes) {
+  if (check_params(nullptr, params) || !bk_bytes || !ks_bytes) return TFHE_HIP_ERR_ARG;
+  size_t rows;
+  blob_sizes(params, bk_bytes, ks_bytes, &rows);
+  return 0;
+}
+
+int tfhe_hip_load_keys(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, const int32_t* bk,
+                       const int32_t* ks_a, const int32_t* ks_b, const double* ks_var) {
+  if (!ctx) return TFHE_HIP_ERR_ARG;
+  if (int rc = check_params(ctx, params)) return rc;
+  if (!bk || !ks_a || !ks_b) return fail(ctx, TFHE_HIP_ERR_ARG, "key pointer is NULL");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (int rc = alloc_keys(ctx, params)) return rc;
+  const tfhe_hip_params& P = ctx->P;
+  // bootstrapping key -> FFT domain
+  {
+    const size_t count = (size_t)P.n * P.l * 2;            // (i, row, col) triples
+    const size_t bytes = count * 2 * kN * sizeof(int32_t);
+    DevBuf raw;
+    HIP_TRY(ctx, hipMalloc(&raw.p, bytes));
+    HIP_TRY(ctx, hipMemcpyAsync(raw.p, bk, bytes, hipMemcpyHostToDevice, ctx->stream));
+    const unsigned grid = (unsigned)((count + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(bk_fft_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (const int32_t*)raw.p,
+                       ctx->tables, ctx->bkfft, (int)count);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  // key-switch key -> padded rows + variances
+  {
+    const size_t rows = (size_t)P.n_ks * P.ks_t * 4;
+    DevBuf da, db;
+    HIP_TRY(ctx, hipMalloc(&da.p, rows * P.n * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMalloc(&db.p, rows * sizeof(int32_t)));
+    HIP_TRY(ctx, hipMemcpyAsync(da.p, ks_a, rows * P.n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(db.p, ks_b, rows * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    const size_t total = rows * (size_t)ctx->row_stride;
+    hipLaunchKernelGGL(ks_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const int32_t*)da.p, (const int32_t*)db.p, P.n, ctx->row_stride, rows,
+                       (int32_t*)ctx->ksblob);
+    HIP_TRY(ctx, hipGetLastError());
+    if (ks_var)
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->ksblob + ctx->ks_rows_bytes, ks_var, rows * sizeof(double),
+                                  hipMemcpyHostToDevice, ctx->stream));
+    else
+      HIP_TRY(ctx, hipMemsetAsync(ctx->ksblob + ctx->ks_rows_bytes, 0, rows * sizeof(double), ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  ctx->have_keys = true;
+  return 0;
+}
+
+int tfhe_hip_export_keys_dev(tfhe_hip_ctx* ctx, void* bk_blob_dev, void* ks_blob_dev) {
+  if (int rc = need_keys(ctx)) return rc;
+  if (!bk_blob_dev || !ks_blob_dev) return fail(ctx, TFHE_HIP_ERR_ARG, "blob pointer is NULL");
+  HIP_TRY(ctx, hipMemcpyAsync(bk_blob_dev, ctx->bkfft, ctx->bk_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ks_blob_dev, ctx->ksblob, ctx->ks_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int tfhe_hip_import_keys_dev(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, const void* bk_blob_dev,
+                             const void* ks_blob_dev) {
+  if (!ctx) return TFHE_HIP_ERR_ARG;
+  if (int rc = check_params(ctx, params)) return rc;
+  if (!bk_blob_dev || !ks_blob_dev) return fail(ctx, TFHE_HIP_ERR_ARG, "blob pointer is NULL");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (int rc = alloc_keys(ctx, params)) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->bkfft, bk_blob_dev, ctx->bk_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->ksblob, ks_blob_dev, ctx->ks_bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->have_keys = true;
+  return 0;
+}
+
+int tfhe_hip_bootstrap_noks_dev(tfhe_hip_ctx* ctx, int32_t mu, const int32_t* a, const int32_t* b,
+                                int32_t* out_a, int32_t* out_b, size_t B) {
+  if (int rc = need_keys(ctx)) return rc;
+  if (B == 0) return 0;
+  if (!a || !b || !out_a || !out_b) return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
+  Scratch s;
+  if (int rc = get_scratch(ctx, B, false, &s)) return rc;
+  if (int rc = launch_prologue(ctx, a, b, nullptr, nullptr, 1, 0, 0, B, s.bara, s.barb)) return rc;
+  return launch_blind_rotate(ctx, s.bara, s.barb, mu, nullptr, out_a, out_b, B);
+}
+
+int tfhe_hip_keyswitch_dev(tfhe_hip_ctx* ctx, const int32_t* a, const int32_t* b, int32_t* out_a,
+                           int32_t* out_b, double* var_out, size_t B) {
+  if (int rc = need_keys(ctx)) return rc;
+  if (B == 0) return 0;
+  if (!a || !b || !out_a || !out_b) return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
+  return launch_keyswitch(ctx, a, b, nullptr, nullptr, 0, out_a, out_b, var_out, B);
+}
+
+int tfhe_hip_bootstrap_dev(tfhe_hip_ctx* ctx, int32_t mu, const int32_t* a, const int32_t* b,
+                           int32_t* out_a, int32_t* out_b, double* var_out, size_t B) {
+  if (int rc = need_keys(ctx)) return rc;
+  if (B == 0) return 0;
+  if (!a || !b || !out_a || !out_b) return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
+  Scratch s;
+  if (int rc = get_scratch(ctx, B, false, &s)) return rc;
+  if (int rc = launch_prologue(ctx, a, b, nullptr, nullptr, 1, 0, 0, B, s.bara, s.barb)) return rc;
+  if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, mu, nullptr, s.ea, s.eb, B)) return rc;
+  return launch_keyswitch(ctx, s.ea, s.eb, nullptr, nullptr, 0, out_a, out_b, var_out, B);
+}
+
+int tfhe_hip_gate_dev(tfhe_hip_ctx* ctx, int gate, const int32_t* ca_a, const int32_t* ca_b,
+                      const int32_t* cb_a, const int32_t* cb_b, const int32_t* cc_a,
+                      const int32_t* cc_b, int32_t* out_a, int32_t* out_b, double* var_out, size_t B) {
+  if (int rc = need_keys(ctx)) return rc;
+  if (B == 0) return 0;
+  if (!ca_a || !ca_b || !cb_a || !cb_b || !out_a || !out_b)
+    return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
+  Scratch s;
+  if (gate == TFHE_HIP_MUX) {                                 // src/gates.rs:239-268
+    if (!cc_a || !cc_b) return fail(ctx, TFHE_HIP_ERR_ARG, "mux needs a third operand");
+    if (int rc = get_scratch(ctx, B, true, &s)) return rc;
+    Weights w1, w2;
+    gate_weights(TFHE_HIP_AND, &w1);
+    gate_weights(TFHE_HIP_ANDNY, &w2);
+    if (int rc = launch_prologue(ctx, ca_a, ca_b, cb_a, cb_b, w1.wa, w1.wb, w1.c, B, s.bara, s.barb)) return rc;
+    if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w1.mu, nullptr, s.ea, s.eb, B)) return rc;
+    if (int rc = launch_prologue(ctx, ca_a, ca_b, cc_a, cc_b, w2.wa, w2.wb, w2.c, B, s.bara, s.barb)) return rc;
+    if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w2.mu, nullptr, s.ea2, s.eb2, B)) return rc;
+    return launch_keyswitch(ctx, s.ea, s.eb, s.ea2, s.eb2, 1 << 29, out_a, out_b, var_out, B);
+  }
+  Weights w;
+  if (!gate_weights(gate, &w)) return fail(ctx, TFHE_HIP_ERR_ARG, "unknown gate id");
+  if (int rc = get_scratch(ctx, B, false, &s)) return rc;
+  if (int rc = launch_prologue(ctx, ca_a, ca_b, cb_a, cb_b, w.wa, w.wb, w.c, B, s.bara, s.barb)) return rc;
+  if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w.mu, nullptr, s.ea, s.eb, B)) return rc;
+  return launch_keyswitch(ctx, s.ea, s.eb, nullptr, nullptr, 0, out_a, out_b, var_out, B);
+}
+
+int tfhe_hip_polymul_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, int32_t* out,
+                         int accumulate, size_t B) {
+  if (!ctx) return TFHE_HIP_ERR_ARG;
+  if (B == 0) return 0;
+  if (!d || !s || !out) return fail(ctx, TFHE_HIP_ERR_ARG, "polynomial pointer is NULL");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t pairs = (B + 1) / 2;
+  const unsigned grid = (unsigned)((pairs + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (accumulate)
+    hipLaunchKernelGGL(polymul_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (int)B);
+  else
+    hipLaunchKernelGGL(polymul_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (int)B);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+// ---- host-pointer entry points: stage, run, copy back ------------------------
+
+#define STAGE_IN(buf, src, bytes)                                                          \
+  DevBuf buf;                                                                              \
+  if (src) {                                                                               \
+    HIP_TRY(ctx, hipMalloc(&buf.p, (bytes)));                                              \
+    HIP_TRY(ctx, hipMemcpyAsync(buf.p, (src), (bytes), hipMemcpyHostToDevice, ctx->stream)); \
+  }
+#define STAGE_OUT(buf, bytes) \
+  DevBuf buf;                 \
+  HIP_TRY(ctx, hipMalloc(&buf.p, (bytes)));
+#define COPY_BACK(dst, buf, bytes) \
+  HIP_TRY(ctx, hipMemcpyAsync((dst), buf.p, (bytes), hipMemcpyDeviceToHost, ctx->stream));
+
+int tfhe_hip_bootstrap(tfhe_hip_ctx* ctx, int32_t mu, const int32_t* a, const int32_t* b,
+                       int32_t* out_a, int32_t* out_b, double* var_out, size_t B) {
+  if (int rc = need_keys(ctx)) return rc;
+  if (B == 0) return 0;
+  if (!a || !b || !out_a || !out_b) return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
+  const size_t n = ctx->P.n;
+  STAGE_IN(da, a, B * n * 4) STAGE_IN(db, b, B * 4)
+  STAGE_OUT(oa, B * n * 4) STAGE_OUT(ob, B * 4) STAGE_OUT(ov, B * 8)
+  if (int rc = tfhe_hip_bootstrap_dev(ctx, mu, (int32_t*)da.p, (int32_t*)db.p, (int32_t*)oa.p,
+                                      (int32_t*)ob.p, var_out ? (double*)ov.p : nullptr, B)) return rc;
+  COPY_BACK(out_a, oa, B * n * 4) COPY_BACK(out_b, ob, B * 4)
+  if (var_out) COPY_BACK(var_out, ov, B * 8)
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int tfhe_hip_bootstrap_noks(tfhe_hip_ctx* ctx, int32_t mu, const int32_t* a, const int32_t* b,
+                            int32_t* out_a, int32_t* out_b, size_t B) {
+  if (int rc = need_keys(ctx)) return rc;
+  if (B == 0) return 0;
+  if (!a || !b || !out_a || !out_b) return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
+  const size_t n = ctx->P.n;
+  STAGE_IN(da, a, B * n * 4) STAGE_IN(db, b, B * 4)
+  STAGE_OUT(oa, B * kN * 4) STAGE_OUT(ob, B * 4)
+  if (int rc = tfhe_hip_bootstrap_noks_dev(ctx, mu, (int32_t*)da.p, (int32_t*)db.p, (int32_t*)oa.p,
+                                           (int32_t*)ob.p, B)) return rc;
+  COPY_BACK(out_a, oa, B * kN * 4) COPY_BACK(out_b, ob, B * 4)
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int tfhe_hip_keyswitch(tfhe_hip_ctx* ctx, const int32_t* a, const int32_t* b, int32_t* out_a,
+                       int32_t* out_b, double* var_out, size_t B) {
+  if (int rc = need_keys(ctx)) return rc;
+  if (B == 0) return 0;
+  if (!a || !b || !out_a || !out_b) return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
+  const size_t n = ctx->P.n;
+  STAGE_IN(da, a, B * kN * 4) STAGE_IN(db, b, B * 4)
+  STAGE_OUT(oa, B * n * 4) STAGE_OUT(ob, B * 4) STAGE_OUT(ov, B * 8)
+  if (int rc = tfhe_hip_keyswitch_dev(ctx, (int32_t*)da.p, (int32_t*)db.p, (int32_t*)oa.p,
+                                      (int32_t*)ob.p, var_out ? (double*)ov.p : nullptr, B)) return rc;
+  COPY_BACK(out_a, oa, B * n * 4) COPY_BACK(out_b, ob, B * 4)
+  if (var_out) COPY_BACK(var_out, ov, B * 8)
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int tfhe_hip_gate(tfhe_hip_ctx* ctx, int gate, const int32_t* ca_a, const int32_t* ca_b,
+                  const int32_t* cb_a, const int32_t* cb_b, const int32_t* cc_a, const int32_t* cc_b,
+                  int32_t* out_a, int32_t* out_b, double* var_out, size_t B) {
+  if (int rc = need_keys(ctx)) return rc;
+  if (B == 0) return 0;
+  if (!ca_a || !ca_b || !cb_a || !cb_b || !out_a || !out_b)
+    return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
+  const size_t n = ctx->P.n;
+  STAGE_IN(daa, ca_a, B * n * 4) STAGE_IN(dab, ca_b, B * 4)
+  STAGE_IN(dba, cb_a, B * n * 4) STAGE_IN(dbb, cb_b, B * 4)
+  STAGE_IN(dca, cc_a, B * n * 4) STAGE_IN(dcb, cc_b, B * 4)
+  STAGE_OUT(oa, B * n * 4) STAGE_OUT(ob, B * 4) STAGE_OUT(ov, B * 8)
+  if (int rc = tfhe_hip_gate_dev(ctx, gate, (int32_t*)daa.p, (int32_t*)dab.p, (int32_t*)dba.p,
+                                 (int32_t*)dbb.p, (int32_t*)dca.p, (int32_t*)dcb.p, (int32_t*)oa.p,
+                                 (int32_t*)ob.p, var_out ? (double*)ov.p : nullptr, B)) return rc;
+  COPY_BACK(out_a, oa, B * n * 4) COPY_BACK(out_b, ob, B * 4)
+  if (var_out) COPY_BACK(var_out, ov, B * 8)
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int tfhe_hip_polymul(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, int32_t* out,
+                     int accumulate, size_t B) {
+  if (!ctx) return TFHE_HIP_ERR_ARG;
+  if (B == 0) return 0;
+  if (!d || !s || !out) return fail(ctx, TFHE_HIP_ERR_ARG, "polynomial pointer is NULL");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t out_bytes = B * (accumulate ? kN : 2 * kN - 1) * sizeof(int32_t);
+  STAGE_IN(dd, d, B * kN * 4) STAGE_IN(ds, s, B * kN * 4)
+  STAGE_IN(dout, out, out_bytes)
+  if (int rc = tfhe_hip_polymul_dev(ctx, (int32_t*)dd.p, (int32_t*)ds.p, (int32_t*)dout.p, accumulate, B)) return rc;
+  COPY_BACK(out, dout, out_bytes)
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int tfhe_hip_extprod(tfhe_hip_ctx* ctx, const int32_t* t, int bk_index, int32_t* out, size_t B) {
+  if (int rc = need_keys(ctx)) return rc;
+  if (B == 0) return 0;
+  if (!t || !out) return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
+  if (bk_index < 0 || bk_index >= ctx->P.n) return fail(ctx, TFHE_HIP_ERR_ARG, "bk_index out of range");
+  const size_t bytes = B * 3 * kN * sizeof(int32_t);
+  STAGE_IN(dt, t, bytes) STAGE_OUT(dout, bytes)
+  const cplx* bk_i = ctx->bkfft + (size_t)bk_index * ctx->P.l * 2 * 2048;
+  const unsigned grid = (unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock);
+  if (ctx->P.l == 2)
+    hipLaunchKernelGGL((extprod_kernel<2, 10>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const int32_t*)dt.p, bk_i, ctx->tables, (int32_t*)dout.p, (int)B);
+  else
+    hipLaunchKernelGGL((extprod_kernel<3, 7>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const int32_t*)dt.p, bk_i, ctx->tables, (int32_t*)dout.p, (int)B);
+  HIP_TRY(ctx, hipGetLastError());
+  COPY_BACK(out, dout, bytes)
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int tfhe_hip_blind_rotate(tfhe_hip_ctx* ctx, int32_t* acc, const int32_t* bara, size_t B) {
+  if (int rc = need_keys(ctx)) return rc;
+  if (B == 0) return 0;
+  if (!acc || !bara) return fail(ctx, TFHE_HIP_ERR_ARG, "pointer is NULL");
+  const size_t bytes = B * 3 * kN * sizeof(int32_t);
+  STAGE_IN(dacc, acc, bytes) STAGE_IN(dbara, bara, B * ctx->P.n * 4)
+  if (int rc = launch_blind_rotate(ctx, (int32_t*)dbara.p, nullptr, 0, (int32_t*)dacc.p, nullptr, nullptr, B)) return rc;
+  COPY_BACK(acc, dacc, bytes)
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,316 @@
+// wave_fft.hpp — f64 FFT machinery for one 64-lane wavefront on gfx950.
+//
+// A zero-padded 2048-point transform is computed by ONE wavefront as two
+// 1024-point transforms, one per half-wave: lanes 0-31 ("half E") own the even
+// bins, lanes 32-63 ("half O") the odd bins.  Inside a half, element
+// n = q + 32*r of a 1024-point sequence lives in lane q, register r, and the
+// 1024-point DFT is the four-step 32 x 32 decomposition:
+//
+//   32-point DFT over the 32 registers of each lane      (straight-line code)
+//   twiddle by w1024^(q*kb)                              (table in LDS)
+//   32 x 32 transpose between lanes and registers        (through LDS, swizzled)
+//   32-point DFT over the registers again
+//
+// No workgroup barrier is used anywhere: every exchange is between lanes of
+// the same wavefront, whose LDS operations execute in program order.
+//
+// Register-index conventions (br = 5-bit bit reversal):
+//   "natural"  : register r holds element q + 32*r
+//   "S-layout" : register p holds element q + 32*br(p)   (spectra are kept so)
+// Forward transforms go natural -> S-layout (two decimation-in-frequency
+// passes), inverse transforms go S-layout -> natural (two decimation-in-time
+// passes), so no explicit reordering is ever executed.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+namespace wfft {
+
+constexpr int kN = 1024;           // polynomial size
+constexpr int kHalfBytes = 16384;  // one 32x32 complex f64 tile
+constexpr int kWaveBytes = 32768;  // exchange area of one wavefront (two halves)
+
+struct alignas(16) cplx {
+  double x, y;
+};
+
+template <int I, int END, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < END) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, END>(f);
+  }
+}
+
+__host__ __device__ constexpr int br5(int v) {
+  return ((v & 1) << 4) | ((v & 2) << 2) | (v & 4) | ((v & 8) >> 2) | ((v & 16) >> 4);
+}
+
+// cos(2*pi*j/32), sin(2*pi*j/32) for j = 0..15, symmetric by construction.
+#define WFFT_C1 0.98078528040323043
+#define WFFT_C2 0.92387953251128674
+#define WFFT_C3 0.83146961230254524
+#define WFFT_C4 0.70710678118654752
+#define WFFT_C5 0.55557023301960222
+#define WFFT_C6 0.38268343236508977
+#define WFFT_C7 0.19509032201612827
+__host__ __device__ constexpr double cos32(int j) {
+  constexpr double t[17] = {1.0, WFFT_C1, WFFT_C2, WFFT_C3, WFFT_C4, WFFT_C5, WFFT_C6, WFFT_C7, 0.0,
+                            -WFFT_C7, -WFFT_C6, -WFFT_C5, -WFFT_C4, -WFFT_C3, -WFFT_C2, -WFFT_C1, -1.0};
+  return t[j];
+}
+__host__ __device__ constexpr double sin32(int j) {
+  constexpr double t[17] = {0.0, WFFT_C7, WFFT_C6, WFFT_C5, WFFT_C4, WFFT_C3, WFFT_C2, WFFT_C1, 1.0,
+                            WFFT_C1, WFFT_C2, WFFT_C3, WFFT_C4, WFFT_C5, WFFT_C6, WFFT_C7, 0.0};
+  return t[j];
+}
+
+// (dr + i di) * w32^(+-TJ); forward uses exp(-2 pi i TJ/32), inverse its conjugate.
+template <int TJ, bool INV>
+__device__ __forceinline__ void mul_w32(double dr, double di, double& outr, double& outi) {
+  if constexpr (TJ == 0) {
+    outr = dr; outi = di;
+  } else if constexpr (TJ == 8) {
+    if constexpr (!INV) { outr = di; outi = -dr; } else { outr = -di; outi = dr; }
+  } else if constexpr (TJ == 4) {
+    if constexpr (!INV) { outr = (dr + di) * WFFT_C4; outi = (di - dr) * WFFT_C4; }
+    else { outr = (dr - di) * WFFT_C4; outi = (di + dr) * WFFT_C4; }
+  } else if constexpr (TJ == 12) {
+    if constexpr (!INV) { outr = (di - dr) * WFFT_C4; outi = -(di + dr) * WFFT_C4; }
+    else { outr = -(dr + di) * WFFT_C4; outi = (dr - di) * WFFT_C4; }
+  } else {
+    constexpr double c = cos32(TJ);
+    constexpr double s = INV ? sin32(TJ) : -sin32(TJ);   // w = c + i s
+    outr = dr * c - di * s;
+    outi = dr * s + di * c;
+  }
+}
+
+// Decimation in frequency, natural in -> bit-reversed out.
+template <int HALF, bool INV>
+__device__ __forceinline__ void dif_stage(double (&re)[32], double (&im)[32]) {
+  static_for<0, 16>([&](auto ic) {
+    constexpr int b = decltype(ic)::value;
+    constexpr int j = b % HALF;
+    constexpr int i0 = (b / HALF) * 2 * HALF + j;
+    constexpr int i1 = i0 + HALF;
+    const double ar = re[i0], ai = im[i0], br_ = re[i1], bi = im[i1];
+    re[i0] = ar + br_;
+    im[i0] = ai + bi;
+    mul_w32<j * (16 / HALF), INV>(ar - br_, ai - bi, re[i1], im[i1]);
+  });
+}
+
+// Decimation in time, bit-reversed in -> natural out.
+template <int HALF, bool INV>
+__device__ __forceinline__ void dit_stage(double (&re)[32], double (&im)[32]) {
+  static_for<0, 16>([&](auto ic) {
+    constexpr int b = decltype(ic)::value;
+    constexpr int j = b % HALF;
+    constexpr int i0 = (b / HALF) * 2 * HALF + j;
+    constexpr int i1 = i0 + HALF;
+    double tr, ti;
+    mul_w32<j * (16 / HALF), INV>(re[i1], im[i1], tr, ti);
+    const double ar = re[i0], ai = im[i0];
+    re[i0] = ar + tr;
+    im[i0] = ai + ti;
+    re[i1] = ar - tr;
+    im[i1] = ai - ti;
+  });
+}
+
+template <bool INV>
+__device__ __forceinline__ void dif32(double (&re)[32], double (&im)[32]) {
+  dif_stage<16, INV>(re, im);
+  dif_stage<8, INV>(re, im);
+  dif_stage<4, INV>(re, im);
+  dif_stage<2, INV>(re, im);
+  dif_stage<1, INV>(re, im);
+}
+
+template <bool INV>
+__device__ __forceinline__ void dit32(double (&re)[32], double (&im)[32]) {
+  dit_stage<1, INV>(re, im);
+  dit_stage<2, INV>(re, im);
+  dit_stage<4, INV>(re, im);
+  dit_stage<8, INV>(re, im);
+  dit_stage<16, INV>(re, im);
+}
+
+// Orders this wavefront's LDS accesses for the compiler.  The hardware runs a
+// wavefront's LDS instructions in program order, so no wait is needed.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ cplx lds_load(const char* base, int byte_off) {
+  return *reinterpret_cast<const cplx*>(base + byte_off);
+}
+__device__ __forceinline__ void lds_store(char* base, int byte_off, double x, double y) {
+  cplx v; v.x = x; v.y = y;
+  *reinterpret_cast<cplx*>(base + byte_off) = v;
+}
+
+// 32 x 32 transpose of one half-wave through its 16 KiB tile.  Element (row,
+// col) sits at row*512 + ((col ^ row) & 31)*16: both the row-wise stores and
+// the column-wise loads are bank-conflict free.
+// IN_BR : register p of the caller holds row index br5(p) (else p).
+// OUT_BR: register p receives column index br5(p) (else p).
+template <bool IN_BR, bool OUT_BR>
+__device__ __forceinline__ void transpose32(double (&re)[32], double (&im)[32], char* tile, int q) {
+  wave_lds_fence();
+  static_for<0, 32>([&](auto ic) {
+    constexpr int p = decltype(ic)::value;
+    constexpr int row = IN_BR ? br5(p) : p;
+    lds_store(tile, row * 512 + ((q ^ row) & 31) * 16, re[p], im[p]);
+  });
+  wave_lds_fence();
+  static_for<0, 32>([&](auto ic) {
+    constexpr int p = decltype(ic)::value;
+    constexpr int col = OUT_BR ? br5(p) : p;
+    const cplx v = lds_load(tile, q * 512 + ((col ^ q) & 31) * 16);
+    re[p] = v.x;
+    im[p] = v.y;
+  });
+  wave_lds_fence();
+}
+
+// Forward 1024-point DFT of one half-wave.  natural in, S-layout out.
+// tE: LDS table, entry [kb*32 + q] = exp(-2 pi i q kb / 1024).
+__device__ __forceinline__ void fft1024_fwd(double (&re)[32], double (&im)[32], char* tile,
+                                            const cplx* tE, int q) {
+  dif32<false>(re, im);
+  static_for<0, 32>([&](auto ic) {
+    constexpr int p = decltype(ic)::value;
+    constexpr int kb = br5(p);
+    if constexpr (kb != 0) {
+      const cplx w = tE[kb * 32 + q];
+      const double xr = re[p], xi = im[p];
+      re[p] = xr * w.x - xi * w.y;
+      im[p] = xr * w.y + xi * w.x;
+    }
+  });
+  transpose32<true, false>(re, im, tile, q);
+  dif32<false>(re, im);
+}
+
+// Inverse (unnormalised) 1024-point DFT of one half-wave.  S-layout in, natural out.
+__device__ __forceinline__ void fft1024_inv(double (&re)[32], double (&im)[32], char* tile,
+                                            const cplx* tE, int q) {
+  dit32<true>(re, im);
+  static_for<0, 32>([&](auto ic) {
+    constexpr int kb = decltype(ic)::value;
+    if constexpr (kb != 0) {
+      const cplx w = tE[kb * 32 + q];          // conjugate twiddle
+      const double xr = re[kb], xi = im[kb];
+      re[kb] = xr * w.x + xi * w.y;
+      im[kb] = xi * w.x - xr * w.y;
+    }
+  });
+  transpose32<false, true>(re, im, tile, q);
+  dit32<true>(re, im);
+}
+
+// Multiply the O half by the twist w2048^(q + 32 r) (CONJ: by its conjugate).
+// tw: LDS table, entry [r*32 + q] = exp(-2 pi i (q + 32 r) / 2048).  natural layout.
+template <bool CONJ>
+__device__ __forceinline__ void twist_odd_half(double (&re)[32], double (&im)[32], const cplx* tw,
+                                               int q, int h) {
+  if (h) {
+    static_for<0, 32>([&](auto ic) {
+      constexpr int r = decltype(ic)::value;
+      const cplx w = tw[r * 32 + q];
+      const double xr = re[r], xi = im[r];
+      if constexpr (!CONJ) {
+        re[r] = xr * w.x - xi * w.y;
+        im[r] = xr * w.y + xi * w.x;
+      } else {
+        re[r] = xr * w.x + xi * w.y;
+        im[r] = xi * w.x - xr * w.y;
+      }
+    });
+  }
+}
+
+// Zero-padded 2048-point forward transform of c[n] = re + i im (n < 1024),
+// natural layout in BOTH halves on entry (each half holds the same data).
+// On exit lane (h, q), register p holds bin k = 2*(q + 32*br5(p)) + h.
+__device__ __forceinline__ void fwd2048(double (&re)[32], double (&im)[32], char* wave_tiles,
+                                        const cplx* tE, const cplx* tw, int q, int h) {
+  twist_odd_half<false>(re, im, tw, q, h);
+  fft1024_fwd(re, im, wave_tiles + h * kHalfBytes, tE, q);
+}
+
+// Value held by lane ^ 32.
+__device__ __forceinline__ double xchg32(double v, int h) {
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)
+  const unsigned lo = (unsigned)__double_as_longlong(v);
+  const unsigned hi = (unsigned)((unsigned long long)__double_as_longlong(v) >> 32);
+  auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  const unsigned rlo = h ? a[0] : a[1];
+  const unsigned rhi = h ? b[0] : b[1];
+  return __longlong_as_double((long long)(((unsigned long long)rhi << 32) | rlo));
+#else
+  return __shfl_xor(v, 32, 64);
+#endif
+}
+
+// First 1024 outputs of the unnormalised inverse 2048-point transform of a
+// spectrum in the layout fwd2048 produces.  On exit lane (h, q), register r
+// holds, for t = q + 32 r: the REAL part of x[t] when h == 0, the IMAGINARY
+// part when h == 1 (returned in out[r]).
+__device__ __forceinline__ void inv2048_first_half(double (&re)[32], double (&im)[32],
+                                                   double (&out)[32], char* wave_tiles,
+                                                   const cplx* tE, const cplx* tw, int q, int h) {
+  fft1024_inv(re, im, wave_tiles + h * kHalfBytes, tE, q);
+  twist_odd_half<true>(re, im, tw, q, h);
+  static_for<0, 32>([&](auto ic) {
+    constexpr int r = decltype(ic)::value;
+    const double send = h ? re[r] : im[r];
+    const double keep = h ? im[r] : re[r];
+    out[r] = keep + xchg32(send, h);
+  });
+}
+
+// Mirror exchange: on entry (re, im) is a spectrum C in fwd2048's layout; on
+// exit (mr, mi) holds conj(C[-k mod 2048]) at the position of bin k.
+__device__ __forceinline__ void mirror2048(const double (&re)[32], const double (&im)[32],
+                                           double (&mr)[32], double (&mi)[32], char* wave_tiles,
+                                           int q, int h) {
+  char* tile = wave_tiles + h * kHalfBytes;
+  wave_lds_fence();
+  static_for<0, 32>([&](auto ic) {
+    constexpr int p = decltype(ic)::value;
+    lds_store(tile, p * 512 + q * 16, re[p], im[p]);
+  });
+  wave_lds_fence();
+  // even bins: m = q + 32 ka -> (1024 - m) mod 1024; odd bins: m -> 1023 - m.
+  const int q2 = h ? (31 - q) : ((32 - q) & 31);
+  const bool wrap = (h == 0) && (q == 0);
+  static_for<0, 32>([&](auto ic) {
+    constexpr int p = decltype(ic)::value;
+    constexpr int p_same = 31 - p;                      // br5(31 - ka) = 31 - br5(ka)
+    constexpr int p_wrap = br5((32 - br5(p)) & 31);     // lane 0 of half E: ka -> -ka mod 32
+    const int p2 = wrap ? p_wrap : p_same;
+    const cplx v = lds_load(tile, p2 * 512 + q2 * 16);
+    mr[p] = v.x;
+    mi[p] = -v.y;
+  });
+  wave_lds_fence();
+}
+
+// Rust `f64::round() as i32`: round half away from zero, saturate, NaN -> 0.
+__device__ __forceinline__ int32_t round_sat_i32(double v) {
+  double r = trunc(v);
+  if (fabs(v - r) >= 0.5) r += copysign(1.0, v);
+  r = fmin(fmax(r, -2147483648.0), 2147483647.0);
+  int32_t i = (int32_t)r;
+  return (v != v) ? 0 : i;
+}
+
+}  // namespace wfft
