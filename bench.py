@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py — bootstrapped NAND gates per second on MI355X.
+
+A step is one batch of 16 384 independent bootstrapped NAND gates (gate
+prologue + blind rotate + sample extract + key switch) on the reference's bench
+parameters (Bit80: n=500, N=1024, k=1, l=2, Bg=2^10, t=8, base 4;
+/root/reference/benches/bootstrapping.rs:10-25).  Inputs, outputs and keys are
+resident in HBM before the timed region.  Keys are synthetic (every entry
+uniform), so no stage degenerates to zeros; the kernels are data independent.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--level 80|128]
+
+For N > 1 launch with torch.distributed.run (one rank per GPU); rank 0 builds
+the keys, their FFT-domain form is broadcast once over RCCL, and every rank
+runs its own batch (weak scaling, no data-path collective).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Algorithmic FP64 work per blind-rotate iteration (real 2N-point FFT = 2.5*2N*log2(2N)
+# flop, pointwise product on N+1 bins = 6 flop each): (k+1) l forward transforms and
+# (k+1)^2 l (pointwise + inverse).
+FLOP_FFT = 2.5 * 2048 * 11
+FLOP_POINTWISE = 6 * 1025
+FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X datasheet, vector FP64
+
+
+def flop_per_iteration(l):
+    return 2 * l * FLOP_FFT + 4 * l * (FLOP_POINTWISE + FLOP_FFT)
+
+
+LEVELS = {80: dict(n=500, l=2, bg_bit=10), 128: dict(n=630, l=3, bg_bit=7)}
+
+
+def synthetic_keys(level, seed):
+    p = LEVELS[level]
+    rng = np.random.default_rng(seed)
+    n, l = p["n"], p["l"]
+
+    def u(shape):
+        return rng.integers(-2**31, 2**31, size=shape, dtype=np.int64).astype(np.int32)
+
+    return dict(bk=u((n, l, 2, 2, 1024)), ks_a=u((n, 8, 4, n)), ks_b=u((n, 8, 4)),
+                ks_var=rng.random((n, 8, 4)) * 1e-9)
+
+
+def cpu_baseline(level):
+    """Times the CPU restatement of tfhe_bootstrap (the checker, oracle/) on the host."""
+    exe = os.path.join(ROOT, "oracle", "cpu_baseline")
+    if not os.path.exists(exe):
+        return None
+    cores = max(1, min(16, os.cpu_count() or 1))
+    per_thread = 2
+    try:
+        out = subprocess.run([exe, str(level), str(cores), str(per_thread)], capture_output=True,
+                             text=True, timeout=600)
+        r = json.loads(out.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001
+        return {"value": None, "error": repr(e)}
+    return {"value": r["gates_per_sec"], "unit": "gates/s", "cores": cores, "kind": "port",
+            "sample": f"{r['gates']} tfhe_bootstrap calls ({per_thread} per thread, {cores} threads "
+                      f"at once) on reference-style Bit{level} keys; C++ restatement of the "
+                      f"reference algorithm with a fresh FFT plan per product as in "
+                      f"src/numerics.rs:235-251, not the Rust binary"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16384)
+    ap.add_argument("--level", type=int, default=80, choices=[80, 128])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import tfhe_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    lv = LEVELS[args.level]
+    params = tfhe_amd.make_params(lv["n"], l=lv["l"], bg_bit=lv["bg_bit"])
+    eng = tfhe_amd.Engine(dev.index)
+    eng.use_torch_stream()
+
+    # keys: rank 0 loads and transforms, the device blobs are broadcast once
+    if rank == 0:
+        K = synthetic_keys(args.level, 0xC0FFEE + 3)
+        eng.load_keys(params, K["bk"], K["ks_a"], K["ks_b"], K["ks_var"])
+    if world > 1:
+        bk_bytes, ks_bytes = eng.key_blob_sizes(params)
+        bk_blob = torch.empty(bk_bytes, dtype=torch.uint8, device=dev)
+        ks_blob = torch.empty(ks_bytes, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            eng.export_keys_dev(bk_blob, ks_blob)
+        dist.broadcast(bk_blob, 0)
+        dist.broadcast(ks_blob, 0)
+        torch.cuda.synchronize()
+        if rank != 0:
+            eng.import_keys_dev(params, bk_blob, ks_blob)
+        del bk_blob, ks_blob
+
+    B, n = args.batch, lv["n"]
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+
+    def rnd(shape):
+        return torch.randint(-2**31, 2**31, shape, dtype=torch.int64, device=dev,
+                             generator=g).to(torch.int32)
+
+    ca_a, ca_b, cb_a, cb_b = rnd((B, n)), rnd((B,)), rnd((B, n)), rnd((B,))
+    out_a = torch.empty((B, n), dtype=torch.int32, device=dev)
+    out_b = torch.empty((B,), dtype=torch.int32, device=dev)
+
+    def step():
+        eng.gate_dev("nand", ca_a, ca_b, cb_a, cb_b, out_a, out_b)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.profile_enable(True)
+    eng.profile_read()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # p50 latency of one gate (B = 1), rank 0 only
+    p50 = None
+    if rank == 0 and not args.no_latency:
+        lat = []
+        for _ in range(21):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            eng.gate_dev("nand", ca_a[:1], ca_b[:1], cb_a[:1], cb_b[:1], out_a[:1], out_b[:1])
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t1)
+        p50 = sorted(lat[1:])[len(lat[1:]) // 2] * 1e3
+
+    if rank == 0:
+        gates = B * world * args.steps
+        value = gates / elapsed
+        br_ms, br_cnt = prof["blind_rotate"]
+        ks_ms, ks_cnt = prof["keyswitch"]
+        br_avg_s = br_ms / max(br_cnt, 1) / 1e3
+        flop_launch = flop_per_iteration(lv["l"]) * lv["n"] * B
+        achieved = flop_launch / br_avg_s / 1e12 if br_avg_s > 0 else 0.0
+        res = {
+            "metric": "bootstrapped NAND gates/sec (node, default params)",
+            "value": value, "unit": "gates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"batched bootstrapped NAND, {B} gates per GPU per step, "
+                                   f"Bit{args.level} (n={lv['n']}, N=1024, k=1, l={lv['l']}, "
+                                   f"Bg=2^{lv['bg_bit']}, ks t=8 base=4), keys resident in HBM",
+                       "batch_per_gpu": B, "security_level": args.level,
+                       "parallelism": f"batch sharded over {world} GPU(s), keys replicated"},
+            "p50_single_gate_latency_ms": p50,
+            "roofline": {"bound": "fp64_valu", "kernel": "blind_rotate_kernel",
+                         "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "flop_per_launch": flop_launch, "avg_launch_ms": br_avg_s * 1e3,
+                         "launches": br_cnt},
+            "kernels_ms_per_launch": {"blind_rotate": br_ms / max(br_cnt, 1),
+                                      "keyswitch": ks_ms / max(ks_cnt, 1),
+                                      "prologue": prof["prologue"][0] / max(prof["prologue"][1], 1)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(args.level)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -64,6 +64,15 @@ int tfhe_hip_set_stream(tfhe_hip_ctx* ctx, void* hip_stream);
 /* Waits for the context's stream. */
 int tfhe_hip_synchronize(tfhe_hip_ctx* ctx);
 
+/* Per-kernel timing with HIP events on the context's stream.  While enabled,
+ * every launch of the gate-prologue, blind-rotate and key-switch kernels is
+ * bracketed by two events.  tfhe_hip_profile_read waits for the stream and
+ * returns, for those three kernels in that order, the summed duration in
+ * milliseconds and the launch count since the last read, then forgets them.
+ * (No counterpart in the reference: measurement support for benches.) */
+int tfhe_hip_profile_enable(tfhe_hip_ctx* ctx, int on);
+int tfhe_hip_profile_read(tfhe_hip_ctx* ctx, double ms_sum[3], int launches[3]);
+
 /* Replaces the key material a CloudKey carries (LweBootstrappingKey,
  * src/lwe.rs:432-446).  Host pointers:
  *   bk     [n][l][k+1][k+1][N]  bk[i].all_sample[row][col].a[poly], first N

@@ -17,6 +17,7 @@ SYMBOLS = [
     "tfhe_hip_bootstrap_dev", "tfhe_hip_bootstrap_noks", "tfhe_hip_bootstrap_noks_dev",
     "tfhe_hip_keyswitch", "tfhe_hip_keyswitch_dev", "tfhe_hip_gate", "tfhe_hip_gate_dev",
     "tfhe_hip_polymul", "tfhe_hip_polymul_dev", "tfhe_hip_extprod", "tfhe_hip_blind_rotate",
+    "tfhe_hip_profile_enable", "tfhe_hip_profile_read",
 ]
 
 
@@ -60,6 +61,8 @@ def load():
                                        f64p, sz]
     for name in ("tfhe_hip_polymul", "tfhe_hip_polymul_dev"):
         getattr(lib, name).argtypes = [vp, i32p, i32p, i32p, C.c_int, sz]
+    lib.tfhe_hip_profile_enable.argtypes = [vp, C.c_int]
+    lib.tfhe_hip_profile_read.argtypes = [vp, C.POINTER(C.c_double * 3), C.POINTER(C.c_int * 3)]
     lib.tfhe_hip_extprod.argtypes = [vp, i32p, C.c_int, i32p, sz]
     lib.tfhe_hip_blind_rotate.argtypes = [vp, i32p, i32p, sz]
     for name in SYMBOLS:

@@ -488,6 +488,9 @@ struct tfhe_hip_ctx {
   // scratch, grown on demand
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  // optional per-kernel timing (tfhe_hip_profile_*)
+  bool profile = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];   // prologue, blind rotate, key switch
 };
 
 namespace {
@@ -548,11 +551,22 @@ int alloc_keys(tfhe_hip_ctx* ctx, const tfhe_hip_params* p) {
   return 0;
 }
 
-template <class K>
-int set_big_lds(tfhe_hip_ctx* ctx, K kernel) {
-  (void)ctx; (void)kernel;
-  return 0;
-}
+// Brackets one kernel launch with events when profiling is on.
+struct ProfileScope {
+  tfhe_hip_ctx* ctx;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int kind;
+  ProfileScope(tfhe_hip_ctx* c, int k) : ctx(c), kind(k) {
+    if (!ctx->profile) return;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+    (void)hipEventRecord(e0, ctx->stream);
+  }
+  ~ProfileScope() {
+    if (!e0) return;
+    (void)hipEventRecord(e1, ctx->stream);
+    ctx->ev[kind].emplace_back(e0, e1);
+  }
+};
 
 struct Weights { int wa, wb; int32_t c, mu; };
 
@@ -598,6 +612,7 @@ int launch_prologue(tfhe_hip_ctx* ctx, const int32_t* ca_a, const int32_t* ca_b,
                     int32_t* barb) {
   const size_t total = B * (size_t)(ctx->P.n + 1);
   const unsigned grid = (unsigned)((total + 255) / 256);
+  ProfileScope prof(ctx, 0);
   hipLaunchKernelGGL(prologue_kernel, dim3(grid), dim3(256), 0, ctx->stream, ca_a, ca_b, cb_a, cb_b,
                      wa, wb, c, ctx->P.n, total, bara, barb);
   HIP_TRY(ctx, hipGetLastError());
@@ -611,6 +626,7 @@ int launch_blind_rotate(tfhe_hip_ctx* ctx, const int32_t* bara, const int32_t* b
   a.acc_io = acc_io; a.out_a = out_a; a.out_b = out_b; a.mu = mu; a.n = ctx->P.n; a.B = (int32_t)B;
   const unsigned grid = (unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock);
   const bool hook = acc_io != nullptr;
+  ProfileScope prof(ctx, 1);
   if (ctx->P.l == 2) {
     if (hook) hipLaunchKernelGGL((blind_rotate_kernel<2, 10, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
     else hipLaunchKernelGGL((blind_rotate_kernel<2, 10, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
@@ -626,6 +642,7 @@ int launch_keyswitch(tfhe_hip_ctx* ctx, const int32_t* in_a, const int32_t* in_b
                      const int32_t* in2_b, int32_t c_b, int32_t* out_a, int32_t* out_b,
                      double* var_out, size_t B) {
   const double* ks_var = (const double*)(ctx->ksblob + ctx->ks_rows_bytes);
+  ProfileScope prof(ctx, 2);
   hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)B), dim3(256), 0, ctx->stream, in_a, in_b, in2_a,
                      in2_b, c_b, kN, (const int32_t*)ctx->ksblob, ks_var, ctx->row_stride, ctx->P.n,
                      ctx->P.n_ks, ctx->P.ks_t, out_a, out_b, var_out);
@@ -708,6 +725,31 @@ int tfhe_hip_synchronize(tfhe_hip_ctx* ctx) {
   if (!ctx) return TFHE_HIP_ERR_ARG;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int tfhe_hip_profile_enable(tfhe_hip_ctx* ctx, int on) {
+  if (!ctx) return TFHE_HIP_ERR_ARG;
+  ctx->profile = on != 0;
+  return 0;
+}
+
+int tfhe_hip_profile_read(tfhe_hip_ctx* ctx, double ms_sum[3], int launches[3]) {
+  if (!ctx || !ms_sum || !launches) return TFHE_HIP_ERR_ARG;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  for (int k = 0; k < 3; k++) {
+    ms_sum[k] = 0.0;
+    launches[k] = (int)ctx->ev[k].size();
+    for (auto& pr : ctx->ev[k]) {
+      float ms = 0.f;
+      (void)hipEventSynchronize(pr.second);
+      if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) ms_sum[k] += ms;
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+    ctx->ev[k].clear();
+  }
   return 0;
 }
 

@@ -90,6 +90,15 @@ class Engine:
         self._check(self.lib.tfhe_hip_set_stream(
             self.ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
+    def profile_enable(self, on=True):
+        self._check(self.lib.tfhe_hip_profile_enable(self.ctx, int(on)))
+
+    def profile_read(self):
+        """{kernel: (summed ms, launches)} since the last read; waits for the stream."""
+        ms, cnt = (C.c_double * 3)(), (C.c_int * 3)()
+        self._check(self.lib.tfhe_hip_profile_read(self.ctx, C.byref(ms), C.byref(cnt)))
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(("prologue", "blind_rotate", "keyswitch"))}
+
     def synchronize(self):
         self._check(self.lib.tfhe_hip_synchronize(self.ctx))
 
