@@ -54,98 +54,122 @@ __device__ __forceinline__ void load_tables(char* lds_tables, const cplx* __rest
 // External product core (src/tgsw.rs:229-264, src/tlwe.rs:149-157,
 // src/numerics.rs:138-155).
 //
-// tt[j][r]: coefficient n = q + 32 r of polynomial j (j = 0..1) of the TLWE
-//           sample being decomposed, present in BOTH half-waves.
-// acc[r]  : lane (h, q) accumulates coefficient t = q + 32 r of result
-//           polynomial u = h.  Every product is rounded and saturated to i32
-//           on its own before the wrapping add, as the reference does.
-// bk      : FFT-domain key of this iteration, [l][2][32][64] cplx.
+// tt_a[r]  : lane (h, q) holds coefficient n = q + 32 r of polynomial j = h of
+//            the TLWE sample being decomposed.
+// acc_a[r] : lane (h, q) accumulates coefficient t = q + 32 r of result
+//            polynomial u = h.  Every product is rounded and saturated to i32
+//            on its own before the wrapping add, as the reference does.
+// Both are handles of values parked in accumulation registers (wfft::agpr_*).
+// bk       : FFT-domain key of this iteration, [l][2][32][64] cplx.
 // ---------------------------------------------------------------------------
 template <int L, int BGBIT>
-__device__ __forceinline__ void extprod_accumulate(const int32_t (&tt)[2][32], int32_t (&acc)[32],
+__device__ __forceinline__ void extprod_accumulate(const unsigned (&tt_a)[32], unsigned (&acc_a)[32],
                                                    const cplx* __restrict__ bk, char* wave_tiles,
                                                    const cplx* tE, const cplx* tw, int lane) {
   const int h = lane >> 5, q = lane & 31;
   constexpr int32_t kHalfBg = 1 << (BGBIT - 1);
   constexpr int32_t kMask = (1 << BGBIT) - 1;
-  double re[32], im[32], hr[32], hi[32];
+  auto accumulate = [&](auto rc, double v) WFFT_INLINE {
+    constexpr int r = decltype(rc)::value;
+    acc_a[r] = wfft::agpr_put((unsigned)wadd((int32_t)wfft::agpr_get(acc_a[r]), wfft::round_sat_i32(v)));
+  };
 #pragma unroll 1
   for (int p = 0; p < L; p++) {
-    // gadget decomposition, src/tgsw.rs:299-328 (offset 0x80000000, tgsw.rs:50-52)
+    double re[32], im[32];
+    unsigned hold[128];      // parked spectrum Z_1
+    // gadget decomposition, src/tgsw.rs:299-328 (offset 0x80000000, tgsw.rs:50-52);
+    // every lane needs the digits of both polynomials: c = d_{p,0} + i d_{p,1}.
     const int decal = 32 - (p + 1) * BGBIT;
-    static_for<0, 32>([&](auto ic) {
+    static_for<0, 32>([&](auto ic) WFFT_INLINE {
       constexpr int r = decltype(ic)::value;
-      const int32_t b0 = wadd(tt[0][r], (int32_t)0x80000000u);
-      const int32_t b1 = wadd(tt[1][r], (int32_t)0x80000000u);
-      re[r] = (double)(((b0 >> decal) & kMask) - kHalfBg);
-      im[r] = (double)(((b1 >> decal) & kMask) - kHalfBg);
+      const int32_t t = (int32_t)wfft::agpr_get(tt_a[r]);
+      const int32_t own = (((wadd(t, (int32_t)0x80000000u)) >> decal) & kMask) - kHalfBg;
+      const int32_t other = wfft::xchg32_i32(own, h);
+      re[r] = (double)(h ? other : own);
+      im[r] = (double)(h ? own : other);
     });
-    // C = FFT(d_{p,0} + i d_{p,1}); the two real spectra are separated with the mirror.
+    // C = FFT(c); the two real spectra are separated with the mirror.
     wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
-    wfft::mirror2048(re, im, hr, hi, wave_tiles, q, h);
-    const cplx* b0 = bk + ((size_t)(p * 2 + 0) * 32) * 64 + lane;
-    const cplx* b1 = bk + ((size_t)(p * 2 + 1) * 32) * 64 + lane;
-    static_for<0, 32>([&](auto ic) {
-      constexpr int s = decltype(ic)::value;
-      const cplx k0 = b0[s * 64];
-      const cplx k1 = b1[s * 64];
-      // D0 = C + Ct, D1 = -i (C - Ct); the factor 1/2 is folded into the key.
-      const double d0r = re[s] + hr[s], d0i = im[s] + hi[s];
-      const double er = re[s] - hr[s], ei = im[s] - hi[s];
-      const double d1r = ei, d1i = -er;
-      re[s] = d0r * k0.x - d0i * k0.y;
-      im[s] = d0r * k0.y + d0i * k0.x;
-      hr[s] = d1r * k1.x - d1i * k1.y;
-      hi[s] = d1r * k1.y + d1i * k1.x;
-    });
-#pragma unroll 1
-    for (int j = 0; j < 2; j++) {
-      if (j == 1) {
-        static_for<0, 32>([&](auto ic) {
-          constexpr int s = decltype(ic)::value;
-          re[s] = hr[s];
-          im[s] = hi[s];
+    {
+      wfft::mirror_store(re, im, wave_tiles, q, h);
+      const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
+      const cplx* b0 = bk + ((size_t)(p * 2 + 0) * 32) * 64 + lane;
+      const cplx* b1 = bk + ((size_t)(p * 2 + 1) * 32) * 64 + lane;
+      // Z_j = D_j * key_j, software pipelined: the key entries and mirrored
+      // bins of group g + 1 are in flight while group g is multiplied.
+      constexpr int G = 4;
+      cplx k0[2][G], k1[2][G], ct[2][G];
+      static_for<0, G>([&](auto ic) WFFT_INLINE {
+        constexpr int e = decltype(ic)::value;
+        k0[0][e] = b0[e * 64];
+        k1[0][e] = b1[e * 64];
+        ct[0][e] = wfft::mirror_load<e>(ml);
+      });
+      static_for<0, 32 / G>([&](auto gc) WFFT_INLINE {
+        constexpr int g = decltype(gc)::value;
+        constexpr int cur = g & 1, nxt = cur ^ 1;
+        if constexpr (g + 1 < 32 / G) {
+          static_for<0, G>([&](auto ic) WFFT_INLINE {
+            constexpr int e = decltype(ic)::value;
+            k0[nxt][e] = b0[((g + 1) * G + e) * 64];
+            k1[nxt][e] = b1[((g + 1) * G + e) * 64];
+            ct[nxt][e] = wfft::mirror_load<(g + 1) * G + e>(ml);
+          });
+        }
+        static_for<0, G>([&](auto ic) WFFT_INLINE {
+          constexpr int e = decltype(ic)::value;
+          constexpr int s = g * G + e;
+          // D0 = C + Ct, D1 = -i (C - Ct); the factor 1/2 is folded into the key.
+          const double hr = ct[cur][e].x, hi = ct[cur][e].y;
+          const double d0r = re[s] + hr, d0i = im[s] + hi;
+          const double er = re[s] - hr, ei = im[s] - hi;
+          const double d1r = ei, d1i = -er;
+          re[s] = d0r * k0[cur][e].x - d0i * k0[cur][e].y;
+          im[s] = d0r * k0[cur][e].y + d0i * k0[cur][e].x;
+          const double z1r = d1r * k1[cur][e].x - d1i * k1[cur][e].y;
+          const double z1i = d1r * k1[cur][e].y + d1i * k1[cur][e].x;
+          wfft::agpr_put_f64(z1r, hold[4 * s + 0], hold[4 * s + 1]);
+          wfft::agpr_put_f64(z1i, hold[4 * s + 2], hold[4 * s + 3]);
         });
-      }
-      double out[32];
-      wfft::inv2048_first_half(re, im, out, wave_tiles, tE, tw, q, h);
-      static_for<0, 32>([&](auto ic) {
-        constexpr int r = decltype(ic)::value;
-        acc[r] = wadd(acc[r], wfft::round_sat_i32(out[r]));
+        __builtin_amdgcn_sched_barrier(0);
       });
     }
+    wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate);
+    static_for<0, 32>([&](auto ic) WFFT_INLINE {
+      constexpr int s = decltype(ic)::value;
+      re[s] = wfft::agpr_get_f64(hold[4 * s + 0], hold[4 * s + 1]);
+      im[s] = wfft::agpr_get_f64(hold[4 * s + 2], hold[4 * s + 3]);
+    });
+    wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate);
   }
 }
 
 // t = X^abar (prev + acc) - acc for polynomials 0 and 1
 // (src/bootstrapping.rs:136-146, src/polynomial.rs:281-313), staged through
-// the wavefront's LDS area.  acc/prev: split layout (lane (h,q) reg r = poly h,
-// coefficient q + 32 r).  tt: both polynomials in every lane.
-__device__ __forceinline__ void rotate_diff(const int32_t (&acc)[32], const int32_t (&prev)[32],
-                                            int32_t (&tt)[2][32], int abar, char* wave_tiles,
+// the wavefront's LDS area; then prev <- acc.  All three arrays are parked:
+// lane (h, q) register r = polynomial h, coefficient q + 32 r.
+__device__ __forceinline__ void rotate_diff(const unsigned (&acc_a)[32], unsigned (&prev_a)[32],
+                                            unsigned (&tt_a)[32], int abar, char* wave_tiles,
                                             int lane) {
   const int h = lane >> 5, q = lane & 31;
-  int32_t* S = reinterpret_cast<int32_t*>(wave_tiles);          // [2][1024] prev + acc
-  int32_t* A = S + 2 * kN;                                      // [2][1024] acc
+  int32_t* S = reinterpret_cast<int32_t*>(wave_tiles) + h * kN;     // [2][1024] prev + acc
   wfft::wave_lds_fence();
-  static_for<0, 32>([&](auto ic) {
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
-    S[h * kN + q + 32 * r] = wadd(prev[r], acc[r]);
-    A[h * kN + q + 32 * r] = acc[r];
+    const int32_t a = (int32_t)wfft::agpr_get(acc_a[r]);
+    S[q + 32 * r] = wadd((int32_t)wfft::agpr_get(prev_a[r]), a);
+    prev_a[r] = wfft::agpr_put((unsigned)a);
   });
   wfft::wave_lds_fence();
   const bool all_neg = (abar == -kN);
-  static_for<0, 32>([&](auto ic) {
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     const int n = q + 32 * r;
     const int src = (n - abar) & (kN - 1);
     const bool neg = all_neg || (abar > 0 && n < abar);
-    static_for<0, 2>([&](auto jc) {
-      constexpr int j = decltype(jc)::value;
-      int32_t v = S[j * kN + src];
-      v = neg ? wneg(v) : v;
-      tt[j][r] = wsub(v, A[j * kN + n]);
-    });
+    int32_t v = S[src];
+    v = neg ? wneg(v) : v;
+    tt_a[r] = wfft::agpr_put((unsigned)wsub(v, (int32_t)wfft::agpr_get(acc_a[r])));
   });
   wfft::wave_lds_fence();
 }
@@ -184,11 +208,13 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
   if (b >= args.B) return;
   char* wave_tiles = lds + wave * wfft::kWaveBytes;
 
-  int32_t acc[32], prev[32];
-  static_for<0, 32>([&](auto ic) {
+  unsigned acc_a[32], prev_a[32], tt_a[32];    // parked in accumulation registers
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
-    prev[r] = 0;                                               // bootstrapping.rs:116-117
-    acc[r] = HOOK ? args.acc_io[((size_t)b * 3 + h) * kN + q + 32 * r] : 0;
+    prev_a[r] = wfft::agpr_put(0u);                            // bootstrapping.rs:116-117
+    acc_a[r] = wfft::agpr_put(
+        HOOK ? (unsigned)args.acc_io[((size_t)b * 3 + h) * kN + q + 32 * r] : 0u);
+    tt_a[r] = wfft::agpr_put(0u);
   });
 
   const int32_t* bara = args.bara + (size_t)b * args.n;
@@ -196,30 +222,26 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
   for (int i = 0; i < args.n; i++) {
     const int abar = __builtin_amdgcn_readfirstlane(bara[i]);
     if (abar == 0) continue;                                   // bootstrapping.rs:122-126
-    int32_t tt[2][32];
-    rotate_diff(acc, prev, tt, abar, wave_tiles, lane);
-    static_for<0, 32>([&](auto ic) {                           // prev <- acc; acc becomes acc + ext
-      constexpr int r = decltype(ic)::value;
-      prev[r] = acc[r];
-    });
-    extprod_accumulate<L, BGBIT>(tt, acc, args.bkfft + (size_t)i * L * 2 * 2048, wave_tiles, tE, tw,
-                                 lane);
+    rotate_diff(acc_a, prev_a, tt_a, abar, wave_tiles, lane);   // also prev <- acc
+    extprod_accumulate<L, BGBIT>(tt_a, acc_a, args.bkfft + (size_t)i * L * 2 * 2048, wave_tiles, tE,
+                                 tw, lane);
   }
 
   if (HOOK) {
-    static_for<0, 32>([&](auto ic) {
+    static_for<0, 32>([&](auto ic) WFFT_INLINE {
       constexpr int r = decltype(ic)::value;
-      args.acc_io[((size_t)b * 3 + h) * kN + q + 32 * r] = acc[r];
+      args.acc_io[((size_t)b * 3 + h) * kN + q + 32 * r] = (int32_t)wfft::agpr_get(acc_a[r]);
     });
   } else {
     // extract_lwe, src/tlwe.rs:159-180 (k = 1): a[0] = acc0[0], a[j] = -acc0[N-j].
     if (h == 0) {
       int32_t* oa = args.out_a + (size_t)b * kN;
-      static_for<0, 32>([&](auto ic) {
+      static_for<0, 32>([&](auto ic) WFFT_INLINE {
         constexpr int r = decltype(ic)::value;
         const int t = q + 32 * r;
-        if (t == 0) oa[0] = acc[r];
-        else oa[kN - t] = wneg(acc[r]);
+        const int32_t v = (int32_t)wfft::agpr_get(acc_a[r]);
+        if (t == 0) oa[0] = v;
+        else oa[kN - t] = wneg(v);
       });
     }
     if (lane == 0) {
@@ -247,17 +269,16 @@ __global__ __launch_bounds__(kBlock, 1) void extprod_kernel(const int32_t* __res
   const int b = blockIdx.x * kWavesPerBlock + wave;
   if (b >= B) return;
   char* wave_tiles = lds + wave * wfft::kWaveBytes;
-  int32_t tt[2][32], acc[32];
-  static_for<0, 32>([&](auto ic) {
+  unsigned tt_a[32], acc_a[32];
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
-    tt[0][r] = t[((size_t)b * 3 + 0) * kN + q + 32 * r];
-    tt[1][r] = t[((size_t)b * 3 + 1) * kN + q + 32 * r];
-    acc[r] = 0;
+    tt_a[r] = wfft::agpr_put((unsigned)t[((size_t)b * 3 + h) * kN + q + 32 * r]);
+    acc_a[r] = wfft::agpr_put(0u);
   });
-  extprod_accumulate<L, BGBIT>(tt, acc, bk_i, wave_tiles, tE, tw, lane);
-  static_for<0, 32>([&](auto ic) {
+  extprod_accumulate<L, BGBIT>(tt_a, acc_a, bk_i, wave_tiles, tE, tw, lane);
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
-    out[((size_t)b * 3 + h) * kN + q + 32 * r] = acc[r];
+    out[((size_t)b * 3 + h) * kN + q + 32 * r] = (int32_t)wfft::agpr_get(acc_a[r]);
     if (h == 0) out[((size_t)b * 3 + 2) * kN + q + 32 * r] = 0;     // tgsw.rs:236-244
   });
 }
@@ -281,14 +302,14 @@ __global__ __launch_bounds__(kBlock, 1) void bk_fft_kernel(const int32_t* __rest
   char* wave_tiles = lds + wave * wfft::kWaveBytes;
   const int32_t* p0 = bk + (size_t)s * 2 * kN;
   double re[32], im[32];
-  static_for<0, 32>([&](auto ic) {
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     re[r] = (double)p0[q + 32 * r];
     im[r] = (double)p0[kN + q + 32 * r];
   });
   wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
   cplx* dst = bkfft + (size_t)s * 2048 + lane;
-  static_for<0, 32>([&](auto ic) {
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int p = decltype(ic)::value;
     cplx v;
     v.x = re[p] * (1.0 / 4096.0);
@@ -321,21 +342,21 @@ __global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __res
   char* wave_tiles = lds + wave * wfft::kWaveBytes;
 
   double re[32], im[32], mr[32], mi[32], dar[32], dai[32], dbr[32], dbi[32];
-  static_for<0, 32>([&](auto ic) {
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     re[r] = (double)d[(size_t)ia * kN + q + 32 * r];
     im[r] = has_b ? (double)d[(size_t)ib * kN + q + 32 * r] : 0.0;
   });
   wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
   wfft::mirror2048(re, im, mr, mi, wave_tiles, q, h);
-  static_for<0, 32>([&](auto ic) {
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int p = decltype(ic)::value;
     dar[p] = re[p] + mr[p];            // 2 D_a
     dai[p] = im[p] + mi[p];
     dbr[p] = im[p] - mi[p];            // 2 D_b = -i (C - Ct)
     dbi[p] = -(re[p] - mr[p]);
   });
-  static_for<0, 32>([&](auto ic) {
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     re[r] = (double)s[(size_t)ia * kN + q + 32 * r];
     im[r] = has_b ? (double)s[(size_t)ib * kN + q + 32 * r] : 0.0;
@@ -343,7 +364,7 @@ __global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __res
   wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
   wfft::mirror2048(re, im, mr, mi, wave_tiles, q, h);
   constexpr double kScale = 1.0 / (4.0 * 2048.0);
-  static_for<0, 32>([&](auto ic) {
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int p = decltype(ic)::value;
     const double sar = re[p] + mr[p], sai = im[p] + mi[p];
     const double sbr = im[p] - mi[p], sbi = -(re[p] - mr[p]);
@@ -357,7 +378,7 @@ __global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __res
   wfft::twist_odd_half<true>(re, im, tw, q, h);
   const int prod = h ? ib : ia;        // half E ends with product a, half O with product b
   const bool live = h ? has_b : true;
-  static_for<0, 32>([&](auto ic) {
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     const int t = q + 32 * r;
     const double send = h ? re[r] : im[r];

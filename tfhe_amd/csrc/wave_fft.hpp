@@ -37,12 +37,31 @@ struct alignas(16) cplx {
   double x, y;
 };
 
+// Every lambda handed to static_for must be inlined at every call site: a
+// register array captured by reference by an out-of-line lambda is forced
+// into scratch memory.
+#define WFFT_INLINE __attribute__((always_inline))
+
 template <int I, int END, class F>
 __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (I < END) {
     f(std::integral_constant<int, I>{});
     static_for<I + 1, END>(f);
   }
+}
+
+// static_for over [0, 32) in chunks of CH iterations; the compiler may not move
+// instructions across chunk boundaries.  Bounds how many loads it hoists at
+// once, i.e. the register pressure of load-heavy loops.
+template <int CH, class F>
+__device__ __forceinline__ void chunked_for32(F&& f) {
+  static_for<0, 32 / CH>([&](auto cc) WFFT_INLINE {
+    constexpr int c = decltype(cc)::value;
+    static_for<0, CH>([&](auto ic) WFFT_INLINE {
+      f(std::integral_constant<int, c * CH + decltype(ic)::value>{});
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  });
 }
 
 __host__ __device__ constexpr int br5(int v) {
@@ -92,7 +111,7 @@ __device__ __forceinline__ void mul_w32(double dr, double di, double& outr, doub
 // Decimation in frequency, natural in -> bit-reversed out.
 template <int HALF, bool INV>
 __device__ __forceinline__ void dif_stage(double (&re)[32], double (&im)[32]) {
-  static_for<0, 16>([&](auto ic) {
+  static_for<0, 16>([&](auto ic) WFFT_INLINE {
     constexpr int b = decltype(ic)::value;
     constexpr int j = b % HALF;
     constexpr int i0 = (b / HALF) * 2 * HALF + j;
@@ -107,7 +126,7 @@ __device__ __forceinline__ void dif_stage(double (&re)[32], double (&im)[32]) {
 // Decimation in time, bit-reversed in -> natural out.
 template <int HALF, bool INV>
 __device__ __forceinline__ void dit_stage(double (&re)[32], double (&im)[32]) {
-  static_for<0, 16>([&](auto ic) {
+  static_for<0, 16>([&](auto ic) WFFT_INLINE {
     constexpr int b = decltype(ic)::value;
     constexpr int j = b % HALF;
     constexpr int i0 = (b / HALF) * 2 * HALF + j;
@@ -163,13 +182,13 @@ __device__ __forceinline__ void lds_store(char* base, int byte_off, double x, do
 template <bool IN_BR, bool OUT_BR>
 __device__ __forceinline__ void transpose32(double (&re)[32], double (&im)[32], char* tile, int q) {
   wave_lds_fence();
-  static_for<0, 32>([&](auto ic) {
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int p = decltype(ic)::value;
     constexpr int row = IN_BR ? br5(p) : p;
     lds_store(tile, row * 512 + ((q ^ row) & 31) * 16, re[p], im[p]);
   });
   wave_lds_fence();
-  static_for<0, 32>([&](auto ic) {
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int p = decltype(ic)::value;
     constexpr int col = OUT_BR ? br5(p) : p;
     const cplx v = lds_load(tile, q * 512 + ((col ^ q) & 31) * 16);
@@ -184,7 +203,7 @@ __device__ __forceinline__ void transpose32(double (&re)[32], double (&im)[32], 
 __device__ __forceinline__ void fft1024_fwd(double (&re)[32], double (&im)[32], char* tile,
                                             const cplx* tE, int q) {
   dif32<false>(re, im);
-  static_for<0, 32>([&](auto ic) {
+  chunked_for32<8>([&](auto ic) WFFT_INLINE {
     constexpr int p = decltype(ic)::value;
     constexpr int kb = br5(p);
     if constexpr (kb != 0) {
@@ -202,7 +221,7 @@ __device__ __forceinline__ void fft1024_fwd(double (&re)[32], double (&im)[32], 
 __device__ __forceinline__ void fft1024_inv(double (&re)[32], double (&im)[32], char* tile,
                                             const cplx* tE, int q) {
   dit32<true>(re, im);
-  static_for<0, 32>([&](auto ic) {
+  chunked_for32<8>([&](auto ic) WFFT_INLINE {
     constexpr int kb = decltype(ic)::value;
     if constexpr (kb != 0) {
       const cplx w = tE[kb * 32 + q];          // conjugate twiddle
@@ -221,7 +240,7 @@ template <bool CONJ>
 __device__ __forceinline__ void twist_odd_half(double (&re)[32], double (&im)[32], const cplx* tw,
                                                int q, int h) {
   if (h) {
-    static_for<0, 32>([&](auto ic) {
+    chunked_for32<8>([&](auto ic) WFFT_INLINE {
       constexpr int r = decltype(ic)::value;
       const cplx w = tw[r * 32 + q];
       const double xr = re[r], xi = im[r];
@@ -263,18 +282,29 @@ __device__ __forceinline__ double xchg32(double v, int h) {
 // First 1024 outputs of the unnormalised inverse 2048-point transform of a
 // spectrum in the layout fwd2048 produces.  On exit lane (h, q), register r
 // holds, for t = q + 32 r: the REAL part of x[t] when h == 0, the IMAGINARY
-// part when h == 1 (returned in out[r]).
+// part when h == 1; each value is handed to sink(integral_constant<r>, value).
+template <class Sink>
 __device__ __forceinline__ void inv2048_first_half(double (&re)[32], double (&im)[32],
-                                                   double (&out)[32], char* wave_tiles,
-                                                   const cplx* tE, const cplx* tw, int q, int h) {
+                                                   char* wave_tiles, const cplx* tE,
+                                                   const cplx* tw, int q, int h, Sink&& sink) {
   fft1024_inv(re, im, wave_tiles + h * kHalfBytes, tE, q);
   twist_odd_half<true>(re, im, tw, q, h);
-  static_for<0, 32>([&](auto ic) {
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     const double send = h ? re[r] : im[r];
     const double keep = h ? im[r] : re[r];
-    out[r] = keep + xchg32(send, h);
+    sink(ic, keep + xchg32(send, h));
   });
+}
+
+// Value of an int32 held by lane ^ 32.
+__device__ __forceinline__ int32_t xchg32_i32(int32_t v, int h) {
+#if __has_builtin(__builtin_amdgcn_permlane32_swap)
+  auto a = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  return (int32_t)(h ? a[0] : a[1]);
+#else
+  return __shfl_xor(v, 32, 64);
+#endif
 }
 
 // Mirror exchange: on entry (re, im) is a spectrum C in fwd2048's layout; on
@@ -284,7 +314,7 @@ __device__ __forceinline__ void mirror2048(const double (&re)[32], const double 
                                            int q, int h) {
   char* tile = wave_tiles + h * kHalfBytes;
   wave_lds_fence();
-  static_for<0, 32>([&](auto ic) {
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int p = decltype(ic)::value;
     lds_store(tile, p * 512 + q * 16, re[p], im[p]);
   });
@@ -292,7 +322,7 @@ __device__ __forceinline__ void mirror2048(const double (&re)[32], const double 
   // even bins: m = q + 32 ka -> (1024 - m) mod 1024; odd bins: m -> 1023 - m.
   const int q2 = h ? (31 - q) : ((32 - q) & 31);
   const bool wrap = (h == 0) && (q == 0);
-  static_for<0, 32>([&](auto ic) {
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int p = decltype(ic)::value;
     constexpr int p_same = 31 - p;                      // br5(31 - ka) = 31 - br5(ka)
     constexpr int p_wrap = br5((32 - br5(p)) & 31);     // lane 0 of half E: ka -> -ka mod 32
@@ -302,6 +332,69 @@ __device__ __forceinline__ void mirror2048(const double (&re)[32], const double 
     mi[p] = -v.y;
   });
   wave_lds_fence();
+}
+
+// Explicit parking of long-lived values in the accumulation registers (AGPRs).
+// gfx950 has 512 registers per lane at one wave per SIMD, but vector ALU
+// instructions address only the first 256; the other 256 are reached with
+// v_accvgpr_write/read.  Values that are idle across a whole FFT (the second
+// spectrum of a pair, the accumulator) are parked there by hand so that the
+// compiler's allocator only has to fit the live FFT working set.
+// (Plain asm, not volatile: these are pure moves, and volatile asm in the
+// function keeps the FFT register arrays from being promoted out of scratch.)
+__device__ __forceinline__ unsigned agpr_put(unsigned v) {
+  unsigned a;
+  asm("v_accvgpr_write_b32 %0, %1" : "=a"(a) : "v"(v));
+  return a;
+}
+__device__ __forceinline__ unsigned agpr_get(unsigned a) {
+  unsigned v;
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+  return v;
+}
+__device__ __forceinline__ void agpr_put_f64(double v, unsigned& lo, unsigned& hi) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  lo = agpr_put((unsigned)u);
+  hi = agpr_put((unsigned)(u >> 32));
+}
+__device__ __forceinline__ double agpr_get_f64(unsigned lo, unsigned hi) {
+  const unsigned long long u = ((unsigned long long)agpr_get(hi) << 32) | agpr_get(lo);
+  return __longlong_as_double((long long)u);
+}
+
+// The mirror exchange in two steps, for callers that consume the mirrored
+// spectrum element by element: mirror_store writes C to the tile, then
+// mirror_load<P> returns conj(C[-k mod 2048]) for the bin k held in register P.
+__device__ __forceinline__ void mirror_store(const double (&re)[32], const double (&im)[32],
+                                             char* wave_tiles, int q, int h) {
+  char* tile = wave_tiles + h * kHalfBytes;
+  wave_lds_fence();
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
+    constexpr int p = decltype(ic)::value;
+    lds_store(tile, p * 512 + q * 16, re[p], im[p]);
+  });
+  wave_lds_fence();
+}
+struct MirrorLane {
+  const char* base;   // tile + partner lane offset
+  bool wrap;          // lane 0 of half E: ka -> -ka mod 32 instead of 31 - ka
+};
+__device__ __forceinline__ MirrorLane mirror_lane(const char* wave_tiles, int q, int h) {
+  MirrorLane m;
+  const int q2 = h ? (31 - q) : ((32 - q) & 31);
+  m.base = wave_tiles + h * kHalfBytes + q2 * 16;
+  m.wrap = (h == 0) && (q == 0);
+  return m;
+}
+template <int P>
+__device__ __forceinline__ cplx mirror_load(const MirrorLane& m) {
+  constexpr int p_same = 31 - P;
+  constexpr int p_wrap = br5((32 - br5(P)) & 31);
+  const cplx v = lds_load(m.base, (m.wrap ? p_wrap : p_same) * 512);
+  cplx r;
+  r.x = v.x;
+  r.y = -v.y;
+  return r;
 }
 
 // Rust `f64::round() as i32`: round half away from zero, saturate, NaN -> 0.
