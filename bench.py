@@ -111,17 +111,8 @@ def main():
         K = synthetic_keys(args.level, 0xC0FFEE + 3)
         eng.load_keys(params, K["bk"], K["ks_a"], K["ks_b"], K["ks_var"])
     if world > 1:
-        bk_bytes, ks_bytes = eng.key_blob_sizes(params)
-        bk_blob = torch.empty(bk_bytes, dtype=torch.uint8, device=dev)
-        ks_blob = torch.empty(ks_bytes, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            eng.export_keys_dev(bk_blob, ks_blob)
-        dist.broadcast(bk_blob, 0)
-        dist.broadcast(ks_blob, 0)
-        torch.cuda.synchronize()
-        if rank != 0:
-            eng.import_keys_dev(params, bk_blob, ks_blob)
-        del bk_blob, ks_blob
+        from tfhe_amd import parallel
+        parallel.replicate_keys(eng, params, dev, src=0)
 
     B, n = args.batch, lv["n"]
     g = torch.Generator(device=dev)

@@ -84,9 +84,10 @@ __device__ __forceinline__ void extprod_accumulate(const unsigned (&tt_a)[32], u
       constexpr int r = decltype(ic)::value;
       const int32_t t = (int32_t)wfft::agpr_get(tt_a[r]);
       const int32_t own = (((wadd(t, (int32_t)0x80000000u)) >> decal) & kMask) - kHalfBg;
-      const int32_t other = wfft::xchg32_i32(own, h);
-      re[r] = (double)(h ? other : own);
-      im[r] = (double)(h ? own : other);
+      unsigned d0 = (unsigned)own, d1 = (unsigned)own;   // (E: digit of poly 0 | O: of poly 1)
+      wfft::swap_halves_u32(d0, d1);                     // d0, d1 = the two digits, in every lane
+      re[r] = (double)(int32_t)d0;
+      im[r] = (double)(int32_t)d1;
     });
     // C = FFT(c); the two real spectra are separated with the mirror.
     wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
@@ -381,20 +382,19 @@ __global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __res
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     const int t = q + 32 * r;
-    const double send = h ? re[r] : im[r];
-    const double keep = h ? im[r] : re[r];
-    const double other = wfft::xchg32(send, h);
-    // half E: keep = Re E, other = Re(tw O); half O: keep = Im(tw O), other = Im E
-    const double lo = keep + other;
-    const double hi_ = h ? (other - keep) : (keep - other);
+    // e = (E: Re E | O: Im E), o = (E: Re twO | O: Im twO)
+    double e = re[r], o = im[r];
+    wfft::swap_halves(e, o);
+    const double lo = e + o;
+    const double hi_ = e - o;
     if (live) {
       if (ACCUMULATE) {
-        int32_t* o = out + (size_t)prod * kN + t;
-        *o = wadd(*o, wfft::round_sat_i32(lo));
+        int32_t* dst = out + (size_t)prod * kN + t;
+        *dst = wadd(*dst, wfft::round_sat_i32(lo));
       } else {
-        int32_t* o = out + (size_t)prod * (2 * kN - 1);
-        o[t] = wfft::round_sat_i32(lo);
-        if (t < kN - 1) o[kN + t] = wfft::round_sat_i32(hi_);
+        int32_t* dst = out + (size_t)prod * (2 * kN - 1);
+        dst[t] = wfft::round_sat_i32(lo);
+        if (t < kN - 1) dst[kN + t] = wfft::round_sat_i32(hi_);
       }
     }
   });

@@ -264,19 +264,30 @@ __device__ __forceinline__ void fwd2048(double (&re)[32], double (&im)[32], char
   fft1024_fwd(re, im, wave_tiles + h * kHalfBytes, tE, q);
 }
 
-// Value held by lane ^ 32.
-__device__ __forceinline__ double xchg32(double v, int h) {
+// Half-wave exchange without selects.  With a = (E: aE | O: aO) and
+// b = (E: bE | O: bO) on entry, on exit a = (E: aE | O: bE), b = (E: aO | O: bO):
+// one v_permlane32_swap_b32 per dword swaps a's upper lanes with b's lower lanes.
+__device__ __forceinline__ void swap_halves_u32(unsigned& a, unsigned& b) {
 #if __has_builtin(__builtin_amdgcn_permlane32_swap)
-  const unsigned lo = (unsigned)__double_as_longlong(v);
-  const unsigned hi = (unsigned)((unsigned long long)__double_as_longlong(v) >> 32);
-  auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-  auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-  const unsigned rlo = h ? a[0] : a[1];
-  const unsigned rhi = h ? b[0] : b[1];
-  return __longlong_as_double((long long)(((unsigned long long)rhi << 32) | rlo));
+  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  a = r[0];
+  b = r[1];
 #else
-  return __shfl_xor(v, 32, 64);
+  const bool up = (threadIdx.x & 32) != 0;
+  const unsigned a2 = __shfl_xor(a, 32, 64), b2 = __shfl_xor(b, 32, 64);
+  const unsigned na = up ? b2 : a, nb = up ? b : a2;
+  a = na;
+  b = nb;
 #endif
+}
+__device__ __forceinline__ void swap_halves(double& a, double& b) {
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a);
+  const unsigned long long ub = (unsigned long long)__double_as_longlong(b);
+  unsigned alo = (unsigned)ua, ahi = (unsigned)(ua >> 32), blo = (unsigned)ub, bhi = (unsigned)(ub >> 32);
+  swap_halves_u32(alo, blo);
+  swap_halves_u32(ahi, bhi);
+  a = __longlong_as_double((long long)(((unsigned long long)ahi << 32) | alo));
+  b = __longlong_as_double((long long)(((unsigned long long)bhi << 32) | blo));
 }
 
 // First 1024 outputs of the unnormalised inverse 2048-point transform of a
@@ -291,20 +302,11 @@ __device__ __forceinline__ void inv2048_first_half(double (&re)[32], double (&im
   twist_odd_half<true>(re, im, tw, q, h);
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
-    const double send = h ? re[r] : im[r];
-    const double keep = h ? im[r] : re[r];
-    sink(ic, keep + xchg32(send, h));
+    // (E: Re E | O: Im E) + (E: Re twO | O: Im twO)
+    double a = re[r], b = im[r];
+    swap_halves(a, b);
+    sink(ic, a + b);
   });
-}
-
-// Value of an int32 held by lane ^ 32.
-__device__ __forceinline__ int32_t xchg32_i32(int32_t v, int h) {
-#if __has_builtin(__builtin_amdgcn_permlane32_swap)
-  auto a = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
-  return (int32_t)(h ? a[0] : a[1]);
-#else
-  return __shfl_xor(v, 32, 64);
-#endif
 }
 
 // Mirror exchange: on entry (re, im) is a spectrum C in fwd2048's layout; on
@@ -398,12 +400,18 @@ __device__ __forceinline__ cplx mirror_load(const MirrorLane& m) {
 }
 
 // Rust `f64::round() as i32`: round half away from zero, saturate, NaN -> 0.
+// v_cvt_i32_f64 truncates, saturates out-of-range values and maps NaN to 0,
+// which is exactly the cast (a C++ cast would be UB out of range).
+// The rounding is v_rndne_f64 (ties to even) where Rust rounds ties away from
+// zero.  The two differ only when the fractional part is exactly 0.5; v is an
+// exactly-integer convolution value plus FFT rounding error, so a tie means an
+// error of 0.5, the point where no f64 FFT (the reference's included) pins the
+// result any more.
 __device__ __forceinline__ int32_t round_sat_i32(double v) {
-  double r = trunc(v);
-  if (fabs(v - r) >= 0.5) r += copysign(1.0, v);
-  r = fmin(fmax(r, -2147483648.0), 2147483647.0);
-  int32_t i = (int32_t)r;
-  return (v != v) ? 0 : i;
+  const double r = rint(v);
+  int32_t i;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(i) : "v"(r));
+  return i;
 }
 
 }  // namespace wfft
