@@ -147,19 +147,27 @@ __device__ __forceinline__ void extprod_accumulate(const unsigned (&tt_a)[32], u
 
 // t = X^abar (prev + acc) - acc for polynomials 0 and 1
 // (src/bootstrapping.rs:136-146, src/polynomial.rs:281-313), staged through
-// the wavefront's LDS area; then prev <- acc.  All three arrays are parked:
-// lane (h, q) register r = polynomial h, coefficient q + 32 r.
-__device__ __forceinline__ void rotate_diff(const unsigned (&acc_a)[32], unsigned (&prev_a)[32],
-                                            unsigned (&tt_a)[32], int abar, char* wave_tiles,
-                                            int lane) {
+// the wavefront's LDS area; then prev <- acc.  acc and t are parked in
+// accumulation registers (lane (h, q) register r = polynomial h, coefficient
+// q + 32 r); the previous accumulator, touched once per iteration, lives in a
+// per-ciphertext slice of global memory with the same indexing.
+__device__ __forceinline__ void rotate_diff(const unsigned (&acc_a)[32], int32_t* __restrict__ prev,
+                                            bool prev_is_zero, unsigned (&tt_a)[32], int abar,
+                                            char* wave_tiles, int lane) {
   const int h = lane >> 5, q = lane & 31;
   int32_t* S = reinterpret_cast<int32_t*>(wave_tiles) + h * kN;     // [2][1024] prev + acc
+  int32_t* pv = prev + h * kN + q;
+  int32_t old[32];
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
+    constexpr int r = decltype(ic)::value;
+    old[r] = prev_is_zero ? 0 : pv[32 * r];
+  });
   wfft::wave_lds_fence();
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     const int32_t a = (int32_t)wfft::agpr_get(acc_a[r]);
-    S[q + 32 * r] = wadd((int32_t)wfft::agpr_get(prev_a[r]), a);
-    prev_a[r] = wfft::agpr_put((unsigned)a);
+    S[q + 32 * r] = wadd(old[r], a);
+    pv[32 * r] = a;
   });
   wfft::wave_lds_fence();
   const bool all_neg = (abar == -kN);
@@ -183,6 +191,7 @@ struct BlindRotateArgs {
   int32_t* acc_io;          // hook mode: [B][3][N] accumulators, updated in place
   int32_t* out_a;           // bootstrap mode: [B][N] extracted mask
   int32_t* out_b;           // bootstrap mode: [B]
+  int32_t* prev;            // scratch [B][2][N]: previous accumulator of each ciphertext
   int32_t mu;
   int32_t n;
   int32_t B;
@@ -209,10 +218,11 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
   if (b >= args.B) return;
   char* wave_tiles = lds + wave * wfft::kWaveBytes;
 
-  unsigned acc_a[32], prev_a[32], tt_a[32];    // parked in accumulation registers
+  unsigned acc_a[32], tt_a[32];    // parked in accumulation registers
+  int32_t* prev = args.prev + (size_t)b * 2 * kN;
+  bool prev_is_zero = true;                                    // bootstrapping.rs:116-117
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
-    prev_a[r] = wfft::agpr_put(0u);                            // bootstrapping.rs:116-117
     acc_a[r] = wfft::agpr_put(
         HOOK ? (unsigned)args.acc_io[((size_t)b * 3 + h) * kN + q + 32 * r] : 0u);
     tt_a[r] = wfft::agpr_put(0u);
@@ -223,7 +233,8 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
   for (int i = 0; i < args.n; i++) {
     const int abar = __builtin_amdgcn_readfirstlane(bara[i]);
     if (abar == 0) continue;                                   // bootstrapping.rs:122-126
-    rotate_diff(acc_a, prev_a, tt_a, abar, wave_tiles, lane);   // also prev <- acc
+    rotate_diff(acc_a, prev, prev_is_zero, tt_a, abar, wave_tiles, lane);   // also prev <- acc
+    prev_is_zero = false;
     extprod_accumulate<L, BGBIT>(tt_a, acc_a, args.bkfft + (size_t)i * L * 2 * 2048, wave_tiles, tE,
                                  tw, lane);
   }
@@ -608,21 +619,23 @@ bool gate_weights(int gate, Weights* w) {
   }
 }
 
-// scratch layout for a batch of B: bara [B][n], barb [B], ea [B][N], eb [B],
-// ea2 [B][N], eb2 [B]
+// scratch layout for a batch of B: bara [B][n], barb [B], prev [B][2][N],
+// ea [B][N], eb [B], ea2 [B][N], eb2 [B]
 struct Scratch {
-  int32_t *bara, *barb, *ea, *eb, *ea2, *eb2;
+  int32_t *bara, *barb, *prev, *ea, *eb, *ea2, *eb2;
 };
 
 int get_scratch(tfhe_hip_ctx* ctx, size_t B, bool two, Scratch* s) {
   const size_t n = ctx->P.n;
   auto up = [](size_t x) { return (x + 63) / 64 * 64; };
-  size_t o_bara = 0, o_barb = o_bara + up(B * n * 4), o_ea = o_barb + up(B * 4);
+  size_t o_bara = 0, o_barb = o_bara + up(B * n * 4), o_prev = o_barb + up(B * 4);
+  size_t o_ea = o_prev + up(B * 2 * kN * 4);
   size_t o_eb = o_ea + up(B * kN * 4), o_ea2 = o_eb + up(B * 4);
   size_t o_eb2 = o_ea2 + (two ? up(B * kN * 4) : 0), total = o_eb2 + (two ? up(B * 4) : 0);
   if (int rc = ensure_scratch(ctx, total)) return rc;
   char* base = (char*)ctx->scratch;
   s->bara = (int32_t*)(base + o_bara); s->barb = (int32_t*)(base + o_barb);
+  s->prev = (int32_t*)(base + o_prev);
   s->ea = (int32_t*)(base + o_ea); s->eb = (int32_t*)(base + o_eb);
   s->ea2 = two ? (int32_t*)(base + o_ea2) : nullptr; s->eb2 = two ? (int32_t*)(base + o_eb2) : nullptr;
   return 0;
@@ -641,9 +654,9 @@ int launch_prologue(tfhe_hip_ctx* ctx, const int32_t* ca_a, const int32_t* ca_b,
 }
 
 int launch_blind_rotate(tfhe_hip_ctx* ctx, const int32_t* bara, const int32_t* barb, int32_t mu,
-                        int32_t* acc_io, int32_t* out_a, int32_t* out_b, size_t B) {
+                        int32_t* prev, int32_t* acc_io, int32_t* out_a, int32_t* out_b, size_t B) {
   BlindRotateArgs a;
-  a.bara = bara; a.barb = barb; a.bkfft = ctx->bkfft; a.tables = ctx->tables;
+  a.bara = bara; a.barb = barb; a.bkfft = ctx->bkfft; a.tables = ctx->tables; a.prev = prev;
   a.acc_io = acc_io; a.out_a = out_a; a.out_b = out_b; a.mu = mu; a.n = ctx->P.n; a.B = (int32_t)B;
   const unsigned grid = (unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock);
   const bool hook = acc_io != nullptr;
@@ -857,7 +870,7 @@ int tfhe_hip_bootstrap_noks_dev(tfhe_hip_ctx* ctx, int32_t mu, const int32_t* a,
   Scratch s;
   if (int rc = get_scratch(ctx, B, false, &s)) return rc;
   if (int rc = launch_prologue(ctx, a, b, nullptr, nullptr, 1, 0, 0, B, s.bara, s.barb)) return rc;
-  return launch_blind_rotate(ctx, s.bara, s.barb, mu, nullptr, out_a, out_b, B);
+  return launch_blind_rotate(ctx, s.bara, s.barb, mu, s.prev, nullptr, out_a, out_b, B);
 }
 
 int tfhe_hip_keyswitch_dev(tfhe_hip_ctx* ctx, const int32_t* a, const int32_t* b, int32_t* out_a,
@@ -876,7 +889,7 @@ int tfhe_hip_bootstrap_dev(tfhe_hip_ctx* ctx, int32_t mu, const int32_t* a, cons
   Scratch s;
   if (int rc = get_scratch(ctx, B, false, &s)) return rc;
   if (int rc = launch_prologue(ctx, a, b, nullptr, nullptr, 1, 0, 0, B, s.bara, s.barb)) return rc;
-  if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, mu, nullptr, s.ea, s.eb, B)) return rc;
+  if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, mu, s.prev, nullptr, s.ea, s.eb, B)) return rc;
   return launch_keyswitch(ctx, s.ea, s.eb, nullptr, nullptr, 0, out_a, out_b, var_out, B);
 }
 
@@ -895,16 +908,16 @@ int tfhe_hip_gate_dev(tfhe_hip_ctx* ctx, int gate, const int32_t* ca_a, const in
     gate_weights(TFHE_HIP_AND, &w1);
     gate_weights(TFHE_HIP_ANDNY, &w2);
     if (int rc = launch_prologue(ctx, ca_a, ca_b, cb_a, cb_b, w1.wa, w1.wb, w1.c, B, s.bara, s.barb)) return rc;
-    if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w1.mu, nullptr, s.ea, s.eb, B)) return rc;
+    if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w1.mu, s.prev, nullptr, s.ea, s.eb, B)) return rc;
     if (int rc = launch_prologue(ctx, ca_a, ca_b, cc_a, cc_b, w2.wa, w2.wb, w2.c, B, s.bara, s.barb)) return rc;
-    if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w2.mu, nullptr, s.ea2, s.eb2, B)) return rc;
+    if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w2.mu, s.prev, nullptr, s.ea2, s.eb2, B)) return rc;
     return launch_keyswitch(ctx, s.ea, s.eb, s.ea2, s.eb2, 1 << 29, out_a, out_b, var_out, B);
   }
   Weights w;
   if (!gate_weights(gate, &w)) return fail(ctx, TFHE_HIP_ERR_ARG, "unknown gate id");
   if (int rc = get_scratch(ctx, B, false, &s)) return rc;
   if (int rc = launch_prologue(ctx, ca_a, ca_b, cb_a, cb_b, w.wa, w.wb, w.c, B, s.bara, s.barb)) return rc;
-  if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w.mu, nullptr, s.ea, s.eb, B)) return rc;
+  if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w.mu, s.prev, nullptr, s.ea, s.eb, B)) return rc;
   return launch_keyswitch(ctx, s.ea, s.eb, nullptr, nullptr, 0, out_a, out_b, var_out, B);
 }
 
@@ -1046,7 +1059,9 @@ int tfhe_hip_blind_rotate(tfhe_hip_ctx* ctx, int32_t* acc, const int32_t* bara, 
   if (!acc || !bara) return fail(ctx, TFHE_HIP_ERR_ARG, "pointer is NULL");
   const size_t bytes = B * 3 * kN * sizeof(int32_t);
   STAGE_IN(dacc, acc, bytes) STAGE_IN(dbara, bara, B * ctx->P.n * 4)
-  if (int rc = launch_blind_rotate(ctx, (int32_t*)dbara.p, nullptr, 0, (int32_t*)dacc.p, nullptr, nullptr, B)) return rc;
+  STAGE_OUT(dprev, B * 2 * kN * sizeof(int32_t))
+  if (int rc = launch_blind_rotate(ctx, (int32_t*)dbara.p, nullptr, 0, (int32_t*)dprev.p,
+                                   (int32_t*)dacc.p, nullptr, nullptr, B)) return rc;
   COPY_BACK(acc, dacc, bytes)
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
