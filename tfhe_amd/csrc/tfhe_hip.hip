@@ -89,58 +89,67 @@ __device__ __forceinline__ void extprod_accumulate(const unsigned (&tt_a)[32], u
       re[r] = (double)(int32_t)d0;
       im[r] = (double)(int32_t)d1;
     });
-    // C = FFT(c); the two real spectra are separated with the mirror.
+    // C = FFT(c); the two real spectra are separated with the mirror:
+    // D_0 = C + Ct, D_1 = -i (C - Ct) with Ct[k] = conj(C[-k]); the factor 1/2
+    // is folded into the key.
     wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+    const cplx* b0 = bk + ((size_t)(p * 2 + 0) * 32) * 64 + lane;
+    const cplx* b1 = bk + ((size_t)(p * 2 + 1) * 32) * 64 + lane;
+    auto load_k0 = [&](auto ic) WFFT_INLINE { return b0[decltype(ic)::value * 64]; };
+    auto load_k1 = [&](auto ic) WFFT_INLINE { return b1[decltype(ic)::value * 64]; };
     {
+      // Z_0 = D_0 * key_0 in place; D_1 is parked.  Key column 0 runs three
+      // groups ahead (its first loads are issued before the mirror stores),
+      // the mirrored bins one group ahead.
+      wfft::Pipe32<4, 3, cplx> k0p;
+      k0p.prologue(load_k0);
       wfft::mirror_store(re, im, wave_tiles, q, h);
       const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
-      const cplx* b0 = bk + ((size_t)(p * 2 + 0) * 32) * 64 + lane;
-      const cplx* b1 = bk + ((size_t)(p * 2 + 1) * 32) * 64 + lane;
-      // Z_j = D_j * key_j, software pipelined: the key entries and mirrored
-      // bins of group g + 1 are in flight while group g is multiplied.
-      constexpr int G = 4;
-      cplx k0[2][G], k1[2][G], ct[2][G];
-      static_for<0, G>([&](auto ic) WFFT_INLINE {
-        constexpr int e = decltype(ic)::value;
-        k0[0][e] = b0[e * 64];
-        k1[0][e] = b1[e * 64];
-        ct[0][e] = wfft::mirror_load<e>(ml);
-      });
-      static_for<0, 32 / G>([&](auto gc) WFFT_INLINE {
+      wfft::Pipe32<4, 1, cplx> ctp;
+      auto load_ct = [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); };
+      ctp.prologue(load_ct);
+      static_for<0, 8>([&](auto gc) WFFT_INLINE {
         constexpr int g = decltype(gc)::value;
-        constexpr int cur = g & 1, nxt = cur ^ 1;
-        if constexpr (g + 1 < 32 / G) {
-          static_for<0, G>([&](auto ic) WFFT_INLINE {
+        if constexpr (g + 3 < 8) {
+          static_for<0, 4>([&](auto ic) WFFT_INLINE {
             constexpr int e = decltype(ic)::value;
-            k0[nxt][e] = b0[((g + 1) * G + e) * 64];
-            k1[nxt][e] = b1[((g + 1) * G + e) * 64];
-            ct[nxt][e] = wfft::mirror_load<(g + 1) * G + e>(ml);
+            k0p.buf[(g + 3) % 4][e] = load_k0(std::integral_constant<int, (g + 3) * 4 + e>{});
           });
         }
-        static_for<0, G>([&](auto ic) WFFT_INLINE {
+        if constexpr (g + 1 < 8) {
+          static_for<0, 4>([&](auto ic) WFFT_INLINE {
+            constexpr int e = decltype(ic)::value;
+            ctp.buf[(g + 1) % 2][e] = load_ct(std::integral_constant<int, (g + 1) * 4 + e>{});
+          });
+        }
+        static_for<0, 4>([&](auto ic) WFFT_INLINE {
           constexpr int e = decltype(ic)::value;
-          constexpr int s = g * G + e;
-          // D0 = C + Ct, D1 = -i (C - Ct); the factor 1/2 is folded into the key.
-          const double hr = ct[cur][e].x, hi = ct[cur][e].y;
-          const double d0r = re[s] + hr, d0i = im[s] + hi;
-          const double er = re[s] - hr, ei = im[s] - hi;
-          const double d1r = ei, d1i = -er;
-          re[s] = d0r * k0[cur][e].x - d0i * k0[cur][e].y;
-          im[s] = d0r * k0[cur][e].y + d0i * k0[cur][e].x;
-          const double z1r = d1r * k1[cur][e].x - d1i * k1[cur][e].y;
-          const double z1i = d1r * k1[cur][e].y + d1i * k1[cur][e].x;
-          wfft::agpr_put_f64(z1r, hold[4 * s + 0], hold[4 * s + 1]);
-          wfft::agpr_put_f64(z1i, hold[4 * s + 2], hold[4 * s + 3]);
+          constexpr int s = g * 4 + e;
+          const cplx ct = ctp.buf[g % 2][e];
+          const cplx ka = k0p.buf[g % 4][e];
+          const double d0r = re[s] + ct.x, d0i = im[s] + ct.y;
+          const double d1r = im[s] - ct.y, d1i = ct.x - re[s];
+          re[s] = d0r * ka.x - d0i * ka.y;
+          im[s] = d0r * ka.y + d0i * ka.x;
+          wfft::agpr_put_f64(d1r, hold[4 * s + 0], hold[4 * s + 1]);
+          wfft::agpr_put_f64(d1i, hold[4 * s + 2], hold[4 * s + 3]);
         });
         __builtin_amdgcn_sched_barrier(0);
       });
     }
     wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate);
-    static_for<0, 32>([&](auto ic) WFFT_INLINE {
-      constexpr int s = decltype(ic)::value;
-      re[s] = wfft::agpr_get_f64(hold[4 * s + 0], hold[4 * s + 1]);
-      im[s] = wfft::agpr_get_f64(hold[4 * s + 2], hold[4 * s + 3]);
-    });
+    {
+      // Z_1 = D_1 * key_1 as D_1 comes back from the accumulation registers.
+      wfft::Pipe32<4, 3, cplx> k1p;
+      k1p.prologue(load_k1);
+      k1p.run(load_k1, [&](auto ic, const cplx& kb) WFFT_INLINE {
+        constexpr int s = decltype(ic)::value;
+        const double d1r = wfft::agpr_get_f64(hold[4 * s + 0], hold[4 * s + 1]);
+        const double d1i = wfft::agpr_get_f64(hold[4 * s + 2], hold[4 * s + 3]);
+        re[s] = d1r * kb.x - d1i * kb.y;
+        im[s] = d1r * kb.y + d1i * kb.x;
+      });
+    }
     wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate);
   }
 }

@@ -64,6 +64,48 @@ __device__ __forceinline__ void chunked_for32(F&& f) {
   });
 }
 
+// Software-pipelined pass over [0, 32) in groups of G: load(i) for group g + D
+// is issued before use(i, value) runs for group g, so that the latency of the
+// loads (LDS tables, key slices) hides behind the arithmetic of D groups.  The
+// compiler may not move instructions across group boundaries, which keeps at
+// most (D + 1) G loaded values live.  prologue() issues the first D groups and
+// may be called well before run().
+template <int G, int D, class T>
+struct Pipe32 {
+  T buf[D + 1][G];
+  template <class LoadF>
+  __device__ __forceinline__ void prologue(LoadF&& load) {
+    static_for<0, D * G>([&](auto ic) WFFT_INLINE {
+      constexpr int i = decltype(ic)::value;
+      buf[i / G][i % G] = load(ic);
+    });
+  }
+  template <class LoadF, class UseF>
+  __device__ __forceinline__ void run(LoadF&& load, UseF&& use) {
+    static_for<0, 32 / G>([&](auto gc) WFFT_INLINE {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (g + D < 32 / G) {
+        static_for<0, G>([&](auto ic) WFFT_INLINE {
+          constexpr int e = decltype(ic)::value;
+          buf[(g + D) % (D + 1)][e] = load(std::integral_constant<int, (g + D) * G + e>{});
+        });
+      }
+      static_for<0, G>([&](auto ic) WFFT_INLINE {
+        constexpr int e = decltype(ic)::value;
+        use(std::integral_constant<int, g * G + e>{}, buf[g % (D + 1)][e]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+};
+
+template <int G, class T, class LoadF, class UseF>
+__device__ __forceinline__ void pipelined_for32(LoadF&& load, UseF&& use) {
+  Pipe32<G, 1, T> pipe;
+  pipe.prologue(load);
+  pipe.run(load, use);
+}
+
 __host__ __device__ constexpr int br5(int v) {
   return ((v & 1) << 4) | ((v & 2) << 2) | (v & 4) | ((v & 8) >> 2) | ((v & 16) >> 4);
 }
@@ -176,20 +218,25 @@ __device__ __forceinline__ void lds_store(char* base, int byte_off, double x, do
 
 // 32 x 32 transpose of one half-wave through its 16 KiB tile.  Element (row,
 // col) sits at row*512 + ((col ^ row) & 31)*16: both the row-wise stores and
-// the column-wise loads are bank-conflict free.
-// IN_BR : register p of the caller holds row index br5(p) (else p).
+// the column-wise loads are bank-conflict free.  The store half is issued
+// element by element by the caller (fused with the twiddle multiplication, so
+// that the LDS store path works while the vector ALU does); transpose_load
+// fetches the columns.
+template <int ROW>
+__device__ __forceinline__ void transpose_store(char* tile, int q, double x, double y) {
+  lds_store(tile, ROW * 512 + ((q ^ ROW) & 31) * 16, x, y);
+}
 // OUT_BR: register p receives column index br5(p) (else p).
-template <bool IN_BR, bool OUT_BR>
-__device__ __forceinline__ void transpose32(double (&re)[32], double (&im)[32], char* tile, int q) {
+// PAIR16: fetch in the order 0, 16, 1, 17, ... (the operand pairs of the first
+//         decimation-in-frequency stage) instead of 0, 1, 2, ...; LDS returns
+//         data in issue order, so arithmetic can start after two loads.
+template <bool OUT_BR, bool PAIR16>
+__device__ __forceinline__ void transpose_load(double (&re)[32], double (&im)[32], const char* tile,
+                                               int q) {
   wave_lds_fence();
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
-    constexpr int p = decltype(ic)::value;
-    constexpr int row = IN_BR ? br5(p) : p;
-    lds_store(tile, row * 512 + ((q ^ row) & 31) * 16, re[p], im[p]);
-  });
-  wave_lds_fence();
-  static_for<0, 32>([&](auto ic) WFFT_INLINE {
-    constexpr int p = decltype(ic)::value;
+    constexpr int i = decltype(ic)::value;
+    constexpr int p = PAIR16 ? ((i >> 1) + 16 * (i & 1)) : i;
     constexpr int col = OUT_BR ? br5(p) : p;
     const cplx v = lds_load(tile, q * 512 + ((col ^ q) & 31) * 16);
     re[p] = v.x;
@@ -203,17 +250,20 @@ __device__ __forceinline__ void transpose32(double (&re)[32], double (&im)[32], 
 __device__ __forceinline__ void fft1024_fwd(double (&re)[32], double (&im)[32], char* tile,
                                             const cplx* tE, int q) {
   dif32<false>(re, im);
-  chunked_for32<8>([&](auto ic) WFFT_INLINE {
-    constexpr int p = decltype(ic)::value;
-    constexpr int kb = br5(p);
-    if constexpr (kb != 0) {
-      const cplx w = tE[kb * 32 + q];
-      const double xr = re[p], xi = im[p];
-      re[p] = xr * w.x - xi * w.y;
-      im[p] = xr * w.y + xi * w.x;
-    }
-  });
-  transpose32<true, false>(re, im, tile, q);
+  pipelined_for32<4, cplx>(
+      [&](auto ic) WFFT_INLINE { return tE[br5(decltype(ic)::value) * 32 + q]; },
+      [&](auto ic, const cplx& w) WFFT_INLINE {
+        constexpr int p = decltype(ic)::value;
+        constexpr int kb = br5(p);
+        double xr = re[p], xi = im[p];
+        if constexpr (kb != 0) {
+          const double yr = xr * w.x - xi * w.y;
+          xi = xr * w.y + xi * w.x;
+          xr = yr;
+        }
+        transpose_store<kb>(tile, q, xr, xi);
+      });
+  transpose_load<false, true>(re, im, tile, q);
   dif32<false>(re, im);
 }
 
@@ -221,16 +271,19 @@ __device__ __forceinline__ void fft1024_fwd(double (&re)[32], double (&im)[32], 
 __device__ __forceinline__ void fft1024_inv(double (&re)[32], double (&im)[32], char* tile,
                                             const cplx* tE, int q) {
   dit32<true>(re, im);
-  chunked_for32<8>([&](auto ic) WFFT_INLINE {
-    constexpr int kb = decltype(ic)::value;
-    if constexpr (kb != 0) {
-      const cplx w = tE[kb * 32 + q];          // conjugate twiddle
-      const double xr = re[kb], xi = im[kb];
-      re[kb] = xr * w.x + xi * w.y;
-      im[kb] = xi * w.x - xr * w.y;
-    }
-  });
-  transpose32<false, true>(re, im, tile, q);
+  pipelined_for32<4, cplx>(
+      [&](auto ic) WFFT_INLINE { return tE[decltype(ic)::value * 32 + q]; },
+      [&](auto ic, const cplx& w) WFFT_INLINE {
+        constexpr int kb = decltype(ic)::value;
+        double xr = re[kb], xi = im[kb];
+        if constexpr (kb != 0) {                       // conjugate twiddle
+          const double yr = xr * w.x + xi * w.y;
+          xi = xi * w.x - xr * w.y;
+          xr = yr;
+        }
+        transpose_store<kb>(tile, q, xr, xi);
+      });
+  transpose_load<true, false>(re, im, tile, q);
   dit32<true>(re, im);
 }
 
@@ -240,18 +293,19 @@ template <bool CONJ>
 __device__ __forceinline__ void twist_odd_half(double (&re)[32], double (&im)[32], const cplx* tw,
                                                int q, int h) {
   if (h) {
-    chunked_for32<8>([&](auto ic) WFFT_INLINE {
-      constexpr int r = decltype(ic)::value;
-      const cplx w = tw[r * 32 + q];
-      const double xr = re[r], xi = im[r];
-      if constexpr (!CONJ) {
-        re[r] = xr * w.x - xi * w.y;
-        im[r] = xr * w.y + xi * w.x;
-      } else {
-        re[r] = xr * w.x + xi * w.y;
-        im[r] = xi * w.x - xr * w.y;
-      }
-    });
+    pipelined_for32<4, cplx>(
+        [&](auto ic) WFFT_INLINE { return tw[decltype(ic)::value * 32 + q]; },
+        [&](auto ic, const cplx& w) WFFT_INLINE {
+          constexpr int r = decltype(ic)::value;
+          const double xr = re[r], xi = im[r];
+          if constexpr (!CONJ) {
+            re[r] = xr * w.x - xi * w.y;
+            im[r] = xr * w.y + xi * w.x;
+          } else {
+            re[r] = xr * w.x + xi * w.y;
+            im[r] = xi * w.x - xr * w.y;
+          }
+        });
   }
 }
 
