@@ -28,6 +28,29 @@
 using wfft::cplx;
 using wfft::static_for;
 
+// Diagnostic build only (-DTFHE_STAMPS): per-phase cycle counts of one
+// wavefront, read back with tfhe_hip_debug_stamps().  In the normal build
+// TFHE_STAMP expands to nothing and no stamp executes.
+#ifdef TFHE_STAMPS
+__device__ unsigned long long g_stamps[16];
+struct StampCtx {
+  unsigned long long acc[16] = {0};
+  unsigned long long last = 0;
+  __device__ __forceinline__ void start() { last = clock64(); }
+  __device__ __forceinline__ void mark(int k) {
+    const unsigned long long t = clock64();
+    acc[k] += t - last;
+    last = t;
+  }
+};
+#define TFHE_STAMP(ctx, k) (ctx).mark(k)
+#else
+struct StampCtx {
+  __device__ __forceinline__ void start() {}
+};
+#define TFHE_STAMP(ctx, k) ((void)0)
+#endif
+
 namespace {
 
 constexpr int kN = 1024;
@@ -65,7 +88,8 @@ __device__ __forceinline__ void load_tables(char* lds_tables, const cplx* __rest
 template <int L, int BGBIT>
 __device__ __forceinline__ void extprod_accumulate(const unsigned (&tt_a)[32], unsigned (&acc_a)[32],
                                                    const cplx* __restrict__ bk, char* wave_tiles,
-                                                   const cplx* tE, const cplx* tw, int lane) {
+                                                   const cplx* tE, const cplx* tw, int lane,
+                                                   StampCtx& st) {
   const int h = lane >> 5, q = lane & 31;
   constexpr int32_t kHalfBg = 1 << (BGBIT - 1);
   constexpr int32_t kMask = (1 << BGBIT) - 1;
@@ -92,7 +116,9 @@ __device__ __forceinline__ void extprod_accumulate(const unsigned (&tt_a)[32], u
     // C = FFT(c); the two real spectra are separated with the mirror:
     // D_0 = C + Ct, D_1 = -i (C - Ct) with Ct[k] = conj(C[-k]); the factor 1/2
     // is folded into the key.
+    TFHE_STAMP(st, 1);
     wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+    TFHE_STAMP(st, 2);
     const cplx* b0 = bk + ((size_t)(p * 2 + 0) * 32) * 64 + lane;
     const cplx* b1 = bk + ((size_t)(p * 2 + 1) * 32) * 64 + lane;
     auto load_k0 = [&](auto ic) WFFT_INLINE { return b0[decltype(ic)::value * 64]; };
@@ -104,6 +130,7 @@ __device__ __forceinline__ void extprod_accumulate(const unsigned (&tt_a)[32], u
       wfft::Pipe32<4, 3, cplx> k0p;
       k0p.prologue(load_k0);
       wfft::mirror_store(re, im, wave_tiles, q, h);
+      TFHE_STAMP(st, 3);
       const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
       wfft::Pipe32<4, 1, cplx> ctp;
       auto load_ct = [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); };
@@ -137,7 +164,9 @@ __device__ __forceinline__ void extprod_accumulate(const unsigned (&tt_a)[32], u
         __builtin_amdgcn_sched_barrier(0);
       });
     }
+    TFHE_STAMP(st, 4);
     wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate);
+    TFHE_STAMP(st, 5);
     {
       // Z_1 = D_1 * key_1 as D_1 comes back from the accumulation registers.
       wfft::Pipe32<4, 3, cplx> k1p;
@@ -150,7 +179,9 @@ __device__ __forceinline__ void extprod_accumulate(const unsigned (&tt_a)[32], u
         im[s] = d1r * kb.y + d1i * kb.x;
       });
     }
+    TFHE_STAMP(st, 6);
     wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate);
+    TFHE_STAMP(st, 7);
   }
 }
 
@@ -238,14 +269,22 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
   });
 
   const int32_t* bara = args.bara + (size_t)b * args.n;
+  StampCtx st;
+  st.start();
 #pragma unroll 1
   for (int i = 0; i < args.n; i++) {
     const int abar = __builtin_amdgcn_readfirstlane(bara[i]);
     if (abar == 0) continue;                                   // bootstrapping.rs:122-126
+    TFHE_STAMP(st, 8);
     rotate_diff(acc_a, prev, prev_is_zero, tt_a, abar, wave_tiles, lane);   // also prev <- acc
     prev_is_zero = false;
+    TFHE_STAMP(st, 0);
     extprod_accumulate<L, BGBIT>(tt_a, acc_a, args.bkfft + (size_t)i * L * 2 * 2048, wave_tiles, tE,
-                                 tw, lane);
+                                 tw, lane, st);
+#ifdef TFHE_STAMPS
+    if (i == args.n - 1 && b == args.B / 2 && lane == 0)
+      for (int k = 0; k < 16; k++) g_stamps[k] = st.acc[k];
+#endif
   }
 
   if (HOOK) {
@@ -296,7 +335,8 @@ __global__ __launch_bounds__(kBlock, 1) void extprod_kernel(const int32_t* __res
     tt_a[r] = wfft::agpr_put((unsigned)t[((size_t)b * 3 + h) * kN + q + 32 * r]);
     acc_a[r] = wfft::agpr_put(0u);
   });
-  extprod_accumulate<L, BGBIT>(tt_a, acc_a, bk_i, wave_tiles, tE, tw, lane);
+  StampCtx st;
+  extprod_accumulate<L, BGBIT>(tt_a, acc_a, bk_i, wave_tiles, tE, tw, lane, st);
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     out[((size_t)b * 3 + h) * kN + q + 32 * r] = (int32_t)wfft::agpr_get(acc_a[r]);
@@ -726,6 +766,12 @@ struct DevBuf {
 }  // namespace
 
 extern "C" {
+
+#ifdef TFHE_STAMPS
+int tfhe_hip_debug_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
 
 int tfhe_hip_create(tfhe_hip_ctx** out, int device) {
   if (!out) return TFHE_HIP_ERR_ARG;
