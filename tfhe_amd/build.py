@@ -21,5 +21,29 @@ def build_library(force=False, verbose=False):
     return OUT
 
 
+HOST_BIN = os.path.join(HERE, "host", "bin")
+
+
+def build_host_programs():
+    """Builds the C++ host-API example and its parity test (g++; they link the library)."""
+    root = os.path.dirname(HERE)
+    os.makedirs(HOST_BIN, exist_ok=True)
+    common = ["g++", "-O2", "-std=c++17", "-fwrapv", "-Wall", "-Wextra"]
+    link = ["-L" + HERE, "-ltfhe_hip", "-Wl,-rpath,$ORIGIN/../.."]
+    jobs = [
+        ([os.path.join(root, "examples", "homomorphic_xor.cpp")], "homomorphic_xor"),
+        ([os.path.join(root, "tests", "host_api_test.cpp"), os.path.join(root, "oracle", "oracle.cpp")],
+         "host_api_test"),
+    ]
+    hdr = os.path.join(HERE, "host", "tfhe.hpp")
+    for srcs, name in jobs:
+        out = os.path.join(HOST_BIN, name)
+        deps = srcs + [hdr, OUT]
+        if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
+            continue
+        subprocess.check_call(common + srcs + ["-o", out] + link)
+    return HOST_BIN
+
+
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))

@@ -1,0 +1,359 @@
+// tfhe.hpp — host-side C++ mirror of the reference crate's public API for the
+// bootstrapped-gate path, on top of the C ABI of include/tfhe_hip.h.
+//
+// Same names, argument meaning and error behaviour as the crate
+// (IsakSundeSingh/tfhe; citations are file:line there):
+//   Parameters::with / default        src/lwe.rs:163-241
+//   generate_keys, encrypt, decrypt   src/encryption.rs:39-62
+//   constant, nand, or, and, xor, xnor, not, nor, andny, andyn, orny, oryn, mux
+//                                     src/gates.rs:12-268
+//   tfhe_bootstrap                    src/bootstrapping.rs:25-29
+// Key generation, encryption and decryption run on the host, as in the crate;
+// every bootstrapped gate is one call into libtfhe_hip.so.  The crate panics on
+// malformed input; here the same conditions throw std::runtime_error.
+//
+// Header-only; link with -ltfhe_hip.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/tfhe_hip.h"
+
+namespace tfhe {
+
+using Torus32 = int32_t;   // src/numerics.rs:15
+
+enum class SecurityLevel { Bit80, Bit128 };   // src/encryption.rs:17-22
+
+// src/numerics.rs:117-120
+constexpr Torus32 encode_message(int32_t mu, int32_t message_space) {
+  int log2 = 0;
+  while (((message_space >> log2) & 1) == 0) log2++;
+  return (Torus32)((uint32_t)mu << (32 - log2));
+}
+
+struct LweParams {            // src/lwe.rs:410-428
+  int32_t n;
+  double alpha_min, alpha_max;
+};
+struct TLweParameters {       // src/tlwe.rs:9-32
+  int32_t n, k;
+  double alpha_min, alpha_max;
+  LweParams extracted_lweparams;
+};
+struct TGswParams {           // src/tgsw.rs:9-68
+  int32_t l, bg_bit;
+  TLweParameters tlwe_params;
+};
+
+struct Parameters {           // src/lwe.rs:155-241
+  int32_t ks_t, ks_base_bit;
+  LweParams in_out_params;
+  TGswParams tgsw_params;
+
+  static Parameters with(SecurityLevel level) {
+    const int32_t N = 1024, K = 1;
+    const double max_stdev = 0.012467;
+    Parameters p;
+    p.ks_base_bit = 2;
+    p.ks_t = 8;
+    int32_t n, l, bg_bit;
+    double ks_stdev, bk_stdev;
+    if (level == SecurityLevel::Bit80) {
+      n = 500; l = 2; bg_bit = 10; ks_stdev = 2.44e-5; bk_stdev = 7.18e-9;
+    } else {
+      n = 630; l = 3; bg_bit = 7; ks_stdev = std::pow(2.0, -15.0); bk_stdev = std::pow(2.0, -15.0);
+    }
+    p.in_out_params = LweParams{n, ks_stdev, max_stdev};
+    TLweParameters acc{N, K, bk_stdev, max_stdev, LweParams{N * K, bk_stdev, max_stdev}};
+    p.tgsw_params = TGswParams{l, bg_bit, acc};
+    return p;
+  }
+  // Parameters::default() is the 128-bit set (src/lwe.rs:235-241).
+  static Parameters default_() { return with(SecurityLevel::Bit128); }
+};
+
+struct LweSample {            // src/lwe.rs:20-27
+  std::vector<Torus32> coefficients;
+  Torus32 b = 0;
+  double current_variance = 0.0;
+};
+
+struct SecretKey {            // src/lwe.rs:264-274
+  Parameters params;
+  std::vector<int32_t> lwe_key;
+};
+
+namespace detail {
+
+inline int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+inline int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+inline int32_t wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+
+// src/numerics.rs:56-58 (Rust's saturating `as i32`)
+inline Torus32 f64_to_torus_32(double d) {
+  double t = std::trunc(d * 4294967296.0);
+  if (t != t) return 0;
+  if (t >= 2147483647.0) return INT32_MAX;
+  if (t <= -2147483648.0) return INT32_MIN;
+  return (Torus32)t;
+}
+
+struct Rng {
+  std::mt19937_64 gen;
+  explicit Rng(uint64_t seed) : gen(seed) {}
+  int32_t torus() { return (int32_t)(gen() >> 32); }
+  int32_t bit() { return (int32_t)(gen() >> 63); }
+  double normal(double sigma) { return std::normal_distribution<double>(0.0, sigma)(gen); }
+};
+
+inline Rng& thread_rng() {      // the crate draws everything from rand::thread_rng()
+  thread_local Rng rng(std::random_device{}());
+  return rng;
+}
+
+// Owns the tfhe_hip context of a CloudKey.
+struct Device {
+  tfhe_hip_ctx* ctx = nullptr;
+  explicit Device(int device) {
+    if (tfhe_hip_create(&ctx, device) != 0)
+      throw std::runtime_error("tfhe_hip_create failed: no usable GPU " + std::to_string(device));
+  }
+  ~Device() { tfhe_hip_destroy(ctx); }
+  Device(const Device&) = delete;
+  Device& operator=(const Device&) = delete;
+  void check(int rc) const {
+    if (rc != 0) throw std::runtime_error(std::string("tfhe_hip: ") + tfhe_hip_last_error(ctx));
+  }
+};
+
+}  // namespace detail
+
+// CloudKey (src/lwe.rs:247-257) with its LweBootstrappingKey (src/lwe.rs:432-446)
+// flattened the way tfhe_hip_load_keys takes it.
+struct CloudKey {
+  Parameters params;
+  std::vector<int32_t> bk;      // [n][l][k+1][k+1][N]
+  std::vector<int32_t> ks_a;    // [n][t][base][n]
+  std::vector<int32_t> ks_b;    // [n][t][base]
+  std::vector<double> ks_var;   // [n][t][base]
+  std::shared_ptr<detail::Device> device;
+
+  tfhe_hip_params hip_params() const {
+    const auto& g = params.tgsw_params;
+    return tfhe_hip_params{params.in_out_params.n, g.tlwe_params.n, g.tlwe_params.k, g.l, g.bg_bit,
+                           params.ks_t, params.ks_base_bit, params.in_out_params.n};
+  }
+  // Uploads the key material to GPU `device_index` (done by generate_keys).
+  void upload(int device_index = 0) {
+    device = std::make_shared<detail::Device>(device_index);
+    tfhe_hip_params hp = hip_params();
+    device->check(tfhe_hip_load_keys(device->ctx, &hp, bk.data(), ks_a.data(), ks_b.data(), ks_var.data()));
+  }
+};
+
+// src/encryption.rs:39-47.  Restates LweKey::generate (src/lwe.rs:294-309),
+// TGswKey::generate (src/tgsw.rs:81-89), LweBootstrappingKey::create
+// (src/lwe.rs:474-492), LweKeySwitchKey::create (src/lwe.rs:530-558),
+// TGswKey::encrypt (src/tgsw.rs:91-94,118-167) and TLweSample::encrypt_zero
+// (src/tlwe.rs:112-134), including their observable quirks: only row 0 of each
+// TGSW sample is encrypted, h = [l, 0, ..] and the second polynomial of a row-0
+// sample is [s*l, 0, .., 0, g_0, ...] of which the first N coefficients matter.
+inline std::pair<SecretKey, CloudKey> generate_keys(const Parameters& params, int device_index = 0) {
+  using namespace detail;
+  Rng& rng = thread_rng();
+  const int32_t n = params.in_out_params.n, N = params.tgsw_params.tlwe_params.n;
+  const int32_t k = params.tgsw_params.tlwe_params.k, l = params.tgsw_params.l;
+  const int32_t t = params.ks_t, bb = params.ks_base_bit, base = 1 << bb;
+
+  SecretKey sk{params, std::vector<int32_t>(n)};
+  for (auto& v : sk.lwe_key) v = rng.bit();
+  std::vector<int32_t> tlwe_key((size_t)(k + 1) * N);
+  for (auto& v : tlwe_key) v = rng.bit();
+
+  CloudKey ck;
+  ck.params = params;
+  // key-switch key: rows for the first n coefficients of the extracted key (src/lwe.rs:461)
+  const size_t rows = (size_t)n * t * base;
+  ck.ks_a.assign(rows * n, 0);
+  ck.ks_b.assign(rows, 0);
+  ck.ks_var.assign(rows, 0.0);
+  {
+    const double alpha = params.in_out_params.alpha_min;
+    const int size_ks = n * t * (base - 1);
+    std::vector<double> noise(size_ks);
+    double sum = 0.0;
+    for (auto& x : noise) { x = rng.normal(alpha); sum += x; }
+    const double error = sum / (double)size_ks;
+    int index = 0;
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < t; j++)
+        for (int h = 1; h < base; h++) {
+          const size_t idx = ((size_t)i * t + j) * base + h;
+          const Torus32 message = wmul(tlwe_key[i] * h, (int32_t)(1u << (32 - (j + 1) * bb)));
+          Torus32 b = wadd(message, f64_to_torus_32(noise[index++] - error));
+          for (int x = 0; x < n; x++) {
+            const int32_t a = rng.torus();
+            ck.ks_a[idx * n + x] = a;
+            b = wadd(b, wmul(a, sk.lwe_key[x]));
+          }
+          ck.ks_b[idx] = b;
+          ck.ks_var[idx] = alpha * alpha;
+        }
+  }
+  // bootstrapping key
+  const double alpha = params.tgsw_params.tlwe_params.alpha_min;
+  ck.bk.assign((size_t)n * l * (k + 1) * (k + 1) * N, 0);
+  for (int i = 0; i < n; i++) {
+    int32_t* s = ck.bk.data() + (size_t)i * l * (k + 1) * (k + 1) * N;
+    for (int j = 0; j <= k; j++) {                    // row 0 only (src/tgsw.rs:118-127)
+      int32_t* smp = s + (size_t)j * (k + 1) * N;
+      for (int u = 0; u < k; u++)
+        for (int x = 0; x < N; x++) smp[(size_t)u * N + x] = rng.torus();
+      // a_last_part + poly_sum is left-padded to 2N-1 entries: N-1 zeros, then the
+      // gaussian terms; only index N-1 of those lands in the first N coefficients.
+      std::vector<Torus32> g(N);
+      for (auto& x : g) x = wadd(0, f64_to_torus_32(rng.normal(alpha)));
+      smp[(size_t)k * N + (N - 1)] = g[0];
+    }
+    for (int j = 0; j <= k; j++)                      // add_mu_int_h with h[0] = l (src/tgsw.rs:43-48,129-167)
+      for (int u = 0; u <= k; u++) {
+        int32_t* c0 = s + ((size_t)j * (k + 1) + u) * N;
+        *c0 = wadd(*c0, wmul(sk.lwe_key[i], l));
+      }
+  }
+  ck.upload(device_index);
+  return {std::move(sk), std::move(ck)};
+}
+
+// src/encryption.rs:50-57, src/lwe.rs:315-331
+inline LweSample encrypt(bool message, const SecretKey& key) {
+  using namespace detail;
+  Rng& rng = thread_rng();
+  const Torus32 e8 = encode_message(1, 8);
+  const Torus32 mu = message ? e8 : -e8;
+  const double alpha = key.params.in_out_params.alpha_min;
+  LweSample s;
+  s.coefficients.resize(key.lwe_key.size());
+  s.b = wadd(mu, f64_to_torus_32(rng.normal(alpha)));
+  for (size_t i = 0; i < s.coefficients.size(); i++) {
+    s.coefficients[i] = rng.torus();
+    s.b = wadd(s.b, wmul(s.coefficients[i], key.lwe_key[i]));
+  }
+  s.current_variance = alpha * alpha;
+  return s;
+}
+
+// src/encryption.rs:60-62, src/lwe.rs:392-406
+inline bool decrypt(const LweSample& sample, const SecretKey& key) {
+  using namespace detail;
+  if (sample.coefficients.size() != key.lwe_key.size())
+    throw std::runtime_error("decrypt: sample and key sizes differ");   // zip_eq panics in the crate
+  int32_t axs = 0;
+  for (size_t i = 0; i < key.lwe_key.size(); i++) axs = wadd(axs, wmul(sample.coefficients[i], key.lwe_key[i]));
+  return wsub(sample.b, axs) > 0;
+}
+
+// src/gates.rs:12-20
+inline LweSample constant(bool value, const CloudKey& bk) {
+  LweSample s;
+  s.coefficients.assign(bk.params.in_out_params.n, 0);
+  s.b = value ? encode_message(1, 8) : -encode_message(1, 8);
+  return s;
+}
+
+// src/gates.rs:122-124, src/lwe.rs:138-151
+inline LweSample not_(const LweSample& ca, const CloudKey&) {
+  LweSample s = ca;
+  for (auto& c : s.coefficients) c = (int32_t)(0u - (uint32_t)c);
+  s.b = (int32_t)(0u - (uint32_t)s.b);
+  return s;
+}
+
+namespace detail {
+
+// Runs one gate id on batches (all samples must have n coefficients).
+inline std::vector<LweSample> gate_batch(int gate, const std::vector<LweSample>& a,
+                                         const std::vector<LweSample>& b,
+                                         const std::vector<LweSample>* c, const CloudKey& bk) {
+  if (!bk.device) throw std::runtime_error("CloudKey has no device context");
+  const size_t B = a.size(), n = bk.params.in_out_params.n;
+  if (b.size() != B || (c && c->size() != B)) throw std::runtime_error("gate: batch sizes differ");
+  auto pack = [&](const std::vector<LweSample>& v, std::vector<int32_t>& m, std::vector<int32_t>& body) {
+    m.resize(B * n);
+    body.resize(B);
+    for (size_t i = 0; i < B; i++) {
+      if (v[i].coefficients.size() != n) throw std::runtime_error("gate: sample size differs from n");
+      std::copy(v[i].coefficients.begin(), v[i].coefficients.end(), m.begin() + i * n);
+      body[i] = v[i].b;
+    }
+  };
+  std::vector<int32_t> aa, ab, ba, bb, ca, cb, oa(B * n), ob(B);
+  std::vector<double> var(B);
+  pack(a, aa, ab);
+  pack(b, ba, bb);
+  if (c) pack(*c, ca, cb);
+  bk.device->check(tfhe_hip_gate(bk.device->ctx, gate, aa.data(), ab.data(), ba.data(), bb.data(),
+                                 c ? ca.data() : nullptr, c ? cb.data() : nullptr, oa.data(),
+                                 ob.data(), var.data(), B));
+  std::vector<LweSample> out(B);
+  for (size_t i = 0; i < B; i++) {
+    out[i].coefficients.assign(oa.begin() + i * n, oa.begin() + (i + 1) * n);
+    out[i].b = ob[i];
+    out[i].current_variance = var[i];
+  }
+  return out;
+}
+
+inline LweSample gate1(int gate, const LweSample& a, const LweSample& b, const CloudKey& bk) {
+  return gate_batch(gate, {a}, {b}, nullptr, bk)[0];
+}
+
+}  // namespace detail
+
+// The ten bootstrapped binary gates (src/gates.rs:23-222) and mux (src/gates.rs:239-268).
+#define TFHE_DEFINE_GATE(NAME, ID)                                                             \
+  inline LweSample NAME(const LweSample& ca, const LweSample& cb, const CloudKey& bk) {        \
+    return detail::gate1(ID, ca, cb, bk);                                                      \
+  }                                                                                            \
+  inline std::vector<LweSample> NAME(const std::vector<LweSample>& ca,                         \
+                                     const std::vector<LweSample>& cb, const CloudKey& bk) {  \
+    return detail::gate_batch(ID, ca, cb, nullptr, bk);                                        \
+  }
+TFHE_DEFINE_GATE(nand, TFHE_HIP_NAND)
+TFHE_DEFINE_GATE(or_, TFHE_HIP_OR)
+TFHE_DEFINE_GATE(and_, TFHE_HIP_AND)
+TFHE_DEFINE_GATE(xor_, TFHE_HIP_XOR)
+TFHE_DEFINE_GATE(xnor, TFHE_HIP_XNOR)
+TFHE_DEFINE_GATE(nor, TFHE_HIP_NOR)
+TFHE_DEFINE_GATE(andny, TFHE_HIP_ANDNY)
+TFHE_DEFINE_GATE(andyn, TFHE_HIP_ANDYN)
+TFHE_DEFINE_GATE(orny, TFHE_HIP_ORNY)
+TFHE_DEFINE_GATE(oryn, TFHE_HIP_ORYN)
+#undef TFHE_DEFINE_GATE
+
+inline LweSample mux(const LweSample& a, const LweSample& b, const LweSample& c, const CloudKey& bk) {
+  std::vector<LweSample> cc{c};
+  return detail::gate_batch(TFHE_HIP_MUX, {a}, {b}, &cc, bk)[0];
+}
+
+// src/bootstrapping.rs:25-29
+inline LweSample tfhe_bootstrap(const CloudKey& bk, Torus32 mu, const LweSample& x) {
+  if (!bk.device) throw std::runtime_error("CloudKey has no device context");
+  const size_t n = bk.params.in_out_params.n;
+  if (x.coefficients.size() != n) throw std::runtime_error("tfhe_bootstrap: sample size differs from n");
+  LweSample out;
+  out.coefficients.resize(n);
+  bk.device->check(tfhe_hip_bootstrap(bk.device->ctx, mu, x.coefficients.data(), &x.b,
+                                      out.coefficients.data(), &out.b, &out.current_variance, 1));
+  return out;
+}
+
+}  // namespace tfhe
