@@ -54,6 +54,20 @@ def synthetic_keys(level, seed):
                 ks_var=rng.random((n, 8, 4)) * 1e-9)
 
 
+def measured_traffic(level, batch):
+    """HBM-side bytes per blind-rotate launch from the committed PMC passes
+    (profiles/r01_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this very
+    command line, corrected as the CDNA4 guide prescribes).  Only valid for the
+    workload it was collected on; otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if level != 80 or batch != 16384 or not os.path.exists(path):
+        return None
+    try:
+        return float(json.load(open(path))["traffic_bytes_per_launch"])
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def cpu_baseline(level):
     """Times the CPU restatement of tfhe_bootstrap (the checker, oracle/) on the host."""
     exe = os.path.join(ROOT, "oracle", "cpu_baseline")
@@ -186,7 +200,8 @@ def main():
             "p50_single_gate_latency_ms": p50,
             "roofline": {"bound": "fp64_valu", "kernel": "blind_rotate_kernel",
                          "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
+                         "traffic": measured_traffic(args.level, B),
                          "flop_per_launch": flop_launch, "avg_launch_ms": br_avg_s * 1e3,
                          "launches": br_cnt},
             "kernels_ms_per_launch": {"blind_rotate": br_ms / max(br_cnt, 1),
