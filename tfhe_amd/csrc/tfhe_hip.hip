@@ -19,6 +19,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -73,24 +74,31 @@ __device__ __forceinline__ void load_tables(char* lds_tables, const cplx* __rest
   __syncthreads();
 }
 
+// Per-wavefront LDS share (wfft::kWaveBytes): the FFT exchange area, then the
+// previous accumulator [2][N] int32 and the sample being decomposed as [N][2]
+// int32 (coefficient-major, so one 8-byte load returns both polynomials).
+constexpr int kPrevOff = wfft::kExchangeBytes;
+constexpr int kTtOff = wfft::kExchangeBytes + 2 * kN * 4;
+static_assert(kTtOff + 2 * kN * 4 <= wfft::kWaveBytes, "per-wavefront LDS share");
+
 // ---------------------------------------------------------------------------
 // External product core (src/tgsw.rs:229-264, src/tlwe.rs:149-157,
 // src/numerics.rs:138-155).
 //
-// tt_a[r]  : lane (h, q) holds coefficient n = q + 32 r of polynomial j = h of
-//            the TLWE sample being decomposed.
+// tt (LDS) : the TLWE sample being decomposed, [N][2] int32.
 // acc_a[r] : lane (h, q) accumulates coefficient t = q + 32 r of result
-//            polynomial u = h.  Every product is rounded and saturated to i32
-//            on its own before the wrapping add, as the reference does.
-// Both are handles of values parked in accumulation registers (wfft::agpr_*).
+//            polynomial u = h; handles of values parked in accumulation
+//            registers (wfft::agpr_*).  Every product is rounded and saturated
+//            to i32 on its own before the wrapping add, as the reference does.
 // bk       : FFT-domain key of this iteration, [l][2][32][64] cplx.
 // ---------------------------------------------------------------------------
 template <int L, int BGBIT>
-__device__ __forceinline__ void extprod_accumulate(const unsigned (&tt_a)[32], unsigned (&acc_a)[32],
-                                                   const cplx* __restrict__ bk, char* wave_tiles,
-                                                   const cplx* tE, const cplx* tw, int lane,
-                                                   StampCtx& st) {
+__device__ __forceinline__ void extprod_accumulate(unsigned (&acc_a)[32], const cplx* __restrict__ bk,
+                                                   char* wave_lds, const cplx* tE, const cplx* tw,
+                                                   int lane, StampCtx& st) {
   const int h = lane >> 5, q = lane & 31;
+  char* wave_tiles = wave_lds;
+  const char* tt = wave_lds + kTtOff + q * 8;
   constexpr int32_t kHalfBg = 1 << (BGBIT - 1);
   constexpr int32_t kMask = (1 << BGBIT) - 1;
   auto accumulate = [&](auto rc, double v) WFFT_INLINE {
@@ -100,18 +108,16 @@ __device__ __forceinline__ void extprod_accumulate(const unsigned (&tt_a)[32], u
 #pragma unroll 1
   for (int p = 0; p < L; p++) {
     double re[32], im[32];
-    unsigned hold[128];      // parked spectrum Z_1
+    unsigned hold[128];      // parked spectrum D_1
     // gadget decomposition, src/tgsw.rs:299-328 (offset 0x80000000, tgsw.rs:50-52);
     // every lane needs the digits of both polynomials: c = d_{p,0} + i d_{p,1}.
     const int decal = 32 - (p + 1) * BGBIT;
+    wfft::wave_lds_fence();
     static_for<0, 32>([&](auto ic) WFFT_INLINE {
       constexpr int r = decltype(ic)::value;
-      const int32_t t = (int32_t)wfft::agpr_get(tt_a[r]);
-      const int32_t own = (((wadd(t, (int32_t)0x80000000u)) >> decal) & kMask) - kHalfBg;
-      unsigned d0 = (unsigned)own, d1 = (unsigned)own;   // (E: digit of poly 0 | O: of poly 1)
-      wfft::swap_halves_u32(d0, d1);                     // d0, d1 = the two digits, in every lane
-      re[r] = (double)(int32_t)d0;
-      im[r] = (double)(int32_t)d1;
+      const int2 t = *reinterpret_cast<const int2*>(tt + r * 256);
+      re[r] = (double)((((wadd(t.x, (int32_t)0x80000000u)) >> decal) & kMask) - kHalfBg);
+      im[r] = (double)((((wadd(t.y, (int32_t)0x80000000u)) >> decal) & kMask) - kHalfBg);
     });
     // C = FFT(c); the two real spectra are separated with the mirror:
     // D_0 = C + Ct, D_1 = -i (C - Ct) with Ct[k] = conj(C[-k]); the factor 1/2
@@ -124,17 +130,26 @@ __device__ __forceinline__ void extprod_accumulate(const unsigned (&tt_a)[32], u
     auto load_k0 = [&](auto ic) WFFT_INLINE { return b0[decltype(ic)::value * 64]; };
     auto load_k1 = [&](auto ic) WFFT_INLINE { return b1[decltype(ic)::value * 64]; };
     {
-      // Z_0 = D_0 * key_0 in place; D_1 is parked.  Key column 0 runs three
-      // groups ahead (its first loads are issued before the mirror stores),
-      // the mirrored bins one group ahead.
+      // Z_0 = D_0 * key_0 in place; D_1 is parked.  The first loads of key
+      // column 0 are issued before the mirror passes.  Real parts go through
+      // the tile first, then the imaginary parts.
       wfft::Pipe32<4, 3, cplx> k0p;
       k0p.prologue(load_k0);
-      wfft::mirror_store(re, im, wave_tiles, q, h);
-      TFHE_STAMP(st, 3);
       const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
-      wfft::Pipe32<4, 1, cplx> ctp;
-      auto load_ct = [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); };
-      ctp.prologue(load_ct);
+      wfft::mirror_store(re, wave_tiles, q, h);
+      TFHE_STAMP(st, 3);
+      wfft::pipelined_for32<4, double>(
+          [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
+          [&](auto ic, const double& ctx) WFFT_INLINE {
+            constexpr int s = decltype(ic)::value;
+            const double c = re[s];
+            re[s] = c + ctx;                                            // Re D_0
+            wfft::agpr_put_f64(ctx - c, hold[4 * s + 2], hold[4 * s + 3]);   // Im D_1
+          });
+      wfft::mirror_store(im, wave_tiles, q, h);
+      auto load_my = [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); };
+      wfft::Pipe32<4, 1, double> myp;
+      myp.prologue(load_my);
       static_for<0, 8>([&](auto gc) WFFT_INLINE {
         constexpr int g = decltype(gc)::value;
         if constexpr (g + 3 < 8) {
@@ -146,20 +161,18 @@ __device__ __forceinline__ void extprod_accumulate(const unsigned (&tt_a)[32], u
         if constexpr (g + 1 < 8) {
           static_for<0, 4>([&](auto ic) WFFT_INLINE {
             constexpr int e = decltype(ic)::value;
-            ctp.buf[(g + 1) % 2][e] = load_ct(std::integral_constant<int, (g + 1) * 4 + e>{});
+            myp.buf[(g + 1) % 2][e] = load_my(std::integral_constant<int, (g + 1) * 4 + e>{});
           });
         }
         static_for<0, 4>([&](auto ic) WFFT_INLINE {
           constexpr int e = decltype(ic)::value;
           constexpr int s = g * 4 + e;
-          const cplx ct = ctp.buf[g % 2][e];
+          const double my = myp.buf[g % 2][e];          // Im C[-k]; Ct = (.., -my)
           const cplx ka = k0p.buf[g % 4][e];
-          const double d0r = re[s] + ct.x, d0i = im[s] + ct.y;
-          const double d1r = im[s] - ct.y, d1i = ct.x - re[s];
+          const double d0r = re[s], d0i = im[s] - my;
+          wfft::agpr_put_f64(im[s] + my, hold[4 * s + 0], hold[4 * s + 1]);   // Re D_1
           re[s] = d0r * ka.x - d0i * ka.y;
           im[s] = d0r * ka.y + d0i * ka.x;
-          wfft::agpr_put_f64(d1r, hold[4 * s + 0], hold[4 * s + 1]);
-          wfft::agpr_put_f64(d1i, hold[4 * s + 2], hold[4 * s + 3]);
         });
         __builtin_amdgcn_sched_barrier(0);
       });
@@ -186,39 +199,35 @@ __device__ __forceinline__ void extprod_accumulate(const unsigned (&tt_a)[32], u
 }
 
 // t = X^abar (prev + acc) - acc for polynomials 0 and 1
-// (src/bootstrapping.rs:136-146, src/polynomial.rs:281-313), staged through
-// the wavefront's LDS area; then prev <- acc.  acc and t are parked in
-// accumulation registers (lane (h, q) register r = polynomial h, coefficient
-// q + 32 r); the previous accumulator, touched once per iteration, lives in a
-// per-ciphertext slice of global memory with the same indexing.
-__device__ __forceinline__ void rotate_diff(const unsigned (&acc_a)[32], int32_t* __restrict__ prev,
-                                            bool prev_is_zero, unsigned (&tt_a)[32], int abar,
-                                            char* wave_tiles, int lane) {
+// (src/bootstrapping.rs:136-146, src/polynomial.rs:281-313), then prev <- acc.
+// acc is parked in accumulation registers (lane (h, q) register r = polynomial
+// h, coefficient q + 32 r); prev and t live in the wavefront's LDS share; the
+// sum prev + acc is staged through the exchange area for the rotation.
+__device__ __forceinline__ void rotate_diff(const unsigned (&acc_a)[32], int abar, char* wave_lds,
+                                            int lane) {
   const int h = lane >> 5, q = lane & 31;
-  int32_t* S = reinterpret_cast<int32_t*>(wave_tiles) + h * kN;     // [2][1024] prev + acc
-  int32_t* pv = prev + h * kN + q;
-  int32_t old[32];
-  static_for<0, 32>([&](auto ic) WFFT_INLINE {
-    constexpr int r = decltype(ic)::value;
-    old[r] = prev_is_zero ? 0 : pv[32 * r];
-  });
+  int32_t* S = reinterpret_cast<int32_t*>(wave_lds) + h * kN;              // [2][N] prev + acc
+  int32_t* pv = reinterpret_cast<int32_t*>(wave_lds + kPrevOff) + h * kN + q;
+  int32_t* tt = reinterpret_cast<int32_t*>(wave_lds + kTtOff) + 2 * q + h;
   wfft::wave_lds_fence();
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     const int32_t a = (int32_t)wfft::agpr_get(acc_a[r]);
-    S[q + 32 * r] = wadd(old[r], a);
+    S[q + 32 * r] = wadd(pv[32 * r], a);
     pv[32 * r] = a;
   });
   wfft::wave_lds_fence();
-  const bool all_neg = (abar == -kN);
+  // X^abar: coefficient n comes from (n - abar) mod N, negated when it wraps
+  // (abar > 0 and n < abar) or when abar = -N (polynomial.rs:281-313).
+  const int base = q - abar;
+  const int wrap = abar > 0 ? base : (abar == -kN ? -(1 << 20) : (1 << 20));
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
-    const int n = q + 32 * r;
-    const int src = (n - abar) & (kN - 1);
-    const bool neg = all_neg || (abar > 0 && n < abar);
+    const int src = (base + 32 * r) & (kN - 1);
+    const bool neg = wrap < -32 * r;
     int32_t v = S[src];
     v = neg ? wneg(v) : v;
-    tt_a[r] = wfft::agpr_put((unsigned)wsub(v, (int32_t)wfft::agpr_get(acc_a[r])));
+    tt[64 * r] = wsub(v, (int32_t)wfft::agpr_get(acc_a[r]));
   });
   wfft::wave_lds_fence();
 }
@@ -231,7 +240,6 @@ struct BlindRotateArgs {
   int32_t* acc_io;          // hook mode: [B][3][N] accumulators, updated in place
   int32_t* out_a;           // bootstrap mode: [B][N] extracted mask
   int32_t* out_b;           // bootstrap mode: [B]
-  int32_t* prev;            // scratch [B][2][N]: previous accumulator of each ciphertext
   int32_t mu;
   int32_t n;
   int32_t B;
@@ -252,35 +260,45 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
   const cplx* tE = reinterpret_cast<const cplx*>(lds_tables);
   const cplx* tw = tE + 1024;
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, kept scalar
   const int h = lane >> 5, q = lane & 31;
-  const int b = blockIdx.x * kWavesPerBlock + wave;
-  if (b >= args.B) return;
   char* wave_tiles = lds + wave * wfft::kWaveBytes;
+  // Workgroups are persistent (one per compute unit): wavefront slot
+  // s = blockIdx.x * 4 + wave takes ciphertexts s, s + slots, s + 2 slots, ...
+  const int slot = blockIdx.x * kWavesPerBlock + wave;
+  const int slots = gridDim.x * kWavesPerBlock;
+  StampCtx st;
+  st.start();
 
-  unsigned acc_a[32], tt_a[32];    // parked in accumulation registers
-  int32_t* prev = args.prev + (size_t)b * 2 * kN;
-  bool prev_is_zero = true;                                    // bootstrapping.rs:116-117
+#pragma unroll 1
+  for (int b = slot; b < args.B; b += slots) {
+  unsigned acc_a[32];              // parked in accumulation registers
+  wfft::wave_lds_fence();
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     acc_a[r] = wfft::agpr_put(
         HOOK ? (unsigned)args.acc_io[((size_t)b * 3 + h) * kN + q + 32 * r] : 0u);
-    tt_a[r] = wfft::agpr_put(0u);
+    // the previous accumulator starts at zero, bootstrapping.rs:116-117
+    reinterpret_cast<int32_t*>(wave_tiles + kPrevOff)[h * kN + q + 32 * r] = 0;
   });
 
   const int32_t* bara = args.bara + (size_t)b * args.n;
-  StampCtx st;
-  st.start();
+  int abar64 = 0;          // the next 64 rotation amounts, one per lane
 #pragma unroll 1
   for (int i = 0; i < args.n; i++) {
-    const int abar = __builtin_amdgcn_readfirstlane(bara[i]);
+    if ((i & 63) == 0) abar64 = (i + lane < args.n) ? bara[i + lane] : 0;
+    const int abar = __builtin_amdgcn_readlane(abar64, i & 63);
     if (abar == 0) continue;                                   // bootstrapping.rs:122-126
+    // Lane-derived addresses are recomputed every iteration (a handful of
+    // instructions) instead of being kept live, or spilled, across the loop.
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
     TFHE_STAMP(st, 8);
-    rotate_diff(acc_a, prev, prev_is_zero, tt_a, abar, wave_tiles, lane);   // also prev <- acc
-    prev_is_zero = false;
+    rotate_diff(acc_a, abar, wave_tiles, ln);                  // also prev <- acc
     TFHE_STAMP(st, 0);
-    extprod_accumulate<L, BGBIT>(tt_a, acc_a, args.bkfft + (size_t)i * L * 2 * 2048, wave_tiles, tE,
-                                 tw, lane, st);
+    extprod_accumulate<L, BGBIT>(acc_a, args.bkfft + (size_t)i * L * 2 * 2048, wave_tiles, tE, tw, ln,
+                                 st);
 #ifdef TFHE_STAMPS
     if (i == args.n - 1 && b == args.B / 2 && lane == 0)
       for (int k = 0; k < 16; k++) g_stamps[k] = st.acc[k];
@@ -311,6 +329,7 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
       args.out_b[b] = barb >= 0 ? args.mu : wneg(args.mu);
     }
   }
+  }
 }
 
 // tgsw_extern_mul_to_tlwe on caller-supplied samples (parity hook).
@@ -329,14 +348,15 @@ __global__ __launch_bounds__(kBlock, 1) void extprod_kernel(const int32_t* __res
   const int b = blockIdx.x * kWavesPerBlock + wave;
   if (b >= B) return;
   char* wave_tiles = lds + wave * wfft::kWaveBytes;
-  unsigned tt_a[32], acc_a[32];
+  unsigned acc_a[32];
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
-    tt_a[r] = wfft::agpr_put((unsigned)t[((size_t)b * 3 + h) * kN + q + 32 * r]);
+    reinterpret_cast<int32_t*>(wave_tiles + kTtOff)[2 * (q + 32 * r) + h] =
+        t[((size_t)b * 3 + h) * kN + q + 32 * r];
     acc_a[r] = wfft::agpr_put(0u);
   });
   StampCtx st;
-  extprod_accumulate<L, BGBIT>(tt_a, acc_a, bk_i, wave_tiles, tE, tw, lane, st);
+  extprod_accumulate<L, BGBIT>(acc_a, bk_i, wave_tiles, tE, tw, lane, st);
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     out[((size_t)b * 3 + h) * kN + q + 32 * r] = (int32_t)wfft::agpr_get(acc_a[r]);
@@ -557,6 +577,7 @@ __global__ void ks_pack_kernel(const int32_t* __restrict__ ks_a, const int32_t* 
 
 struct tfhe_hip_ctx {
   int device = 0;
+  int num_cus = 256;
   hipStream_t stream = nullptr;
   std::string err;
   bool have_keys = false;
@@ -668,23 +689,22 @@ bool gate_weights(int gate, Weights* w) {
   }
 }
 
-// scratch layout for a batch of B: bara [B][n], barb [B], prev [B][2][N],
+// scratch layout for a batch of B: bara [B][n], barb [B],
 // ea [B][N], eb [B], ea2 [B][N], eb2 [B]
 struct Scratch {
-  int32_t *bara, *barb, *prev, *ea, *eb, *ea2, *eb2;
+  int32_t *bara, *barb, *ea, *eb, *ea2, *eb2;
 };
 
 int get_scratch(tfhe_hip_ctx* ctx, size_t B, bool two, Scratch* s) {
   const size_t n = ctx->P.n;
   auto up = [](size_t x) { return (x + 63) / 64 * 64; };
-  size_t o_bara = 0, o_barb = o_bara + up(B * n * 4), o_prev = o_barb + up(B * 4);
-  size_t o_ea = o_prev + up(B * 2 * kN * 4);
+  size_t o_bara = 0, o_barb = o_bara + up(B * n * 4);
+  size_t o_ea = o_barb + up(B * 4);
   size_t o_eb = o_ea + up(B * kN * 4), o_ea2 = o_eb + up(B * 4);
   size_t o_eb2 = o_ea2 + (two ? up(B * kN * 4) : 0), total = o_eb2 + (two ? up(B * 4) : 0);
   if (int rc = ensure_scratch(ctx, total)) return rc;
   char* base = (char*)ctx->scratch;
   s->bara = (int32_t*)(base + o_bara); s->barb = (int32_t*)(base + o_barb);
-  s->prev = (int32_t*)(base + o_prev);
   s->ea = (int32_t*)(base + o_ea); s->eb = (int32_t*)(base + o_eb);
   s->ea2 = two ? (int32_t*)(base + o_ea2) : nullptr; s->eb2 = two ? (int32_t*)(base + o_eb2) : nullptr;
   return 0;
@@ -703,11 +723,13 @@ int launch_prologue(tfhe_hip_ctx* ctx, const int32_t* ca_a, const int32_t* ca_b,
 }
 
 int launch_blind_rotate(tfhe_hip_ctx* ctx, const int32_t* bara, const int32_t* barb, int32_t mu,
-                        int32_t* prev, int32_t* acc_io, int32_t* out_a, int32_t* out_b, size_t B) {
+                        int32_t* acc_io, int32_t* out_a, int32_t* out_b, size_t B) {
   BlindRotateArgs a;
-  a.bara = bara; a.barb = barb; a.bkfft = ctx->bkfft; a.tables = ctx->tables; a.prev = prev;
+  a.bara = bara; a.barb = barb; a.bkfft = ctx->bkfft; a.tables = ctx->tables;
   a.acc_io = acc_io; a.out_a = out_a; a.out_b = out_b; a.mu = mu; a.n = ctx->P.n; a.B = (int32_t)B;
-  const unsigned grid = (unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock);
+  // one persistent workgroup per compute unit (160 KiB of LDS each)
+  const unsigned grid = (unsigned)std::min<size_t>((B + kWavesPerBlock - 1) / kWavesPerBlock,
+                                                   (size_t)ctx->num_cus);
   const bool hook = acc_io != nullptr;
   ProfileScope prof(ctx, 1);
   if (ctx->P.l == 2) {
@@ -781,6 +803,9 @@ int tfhe_hip_create(tfhe_hip_ctx** out, int device) {
   tfhe_hip_ctx* ctx = new tfhe_hip_ctx();
   ctx->device = device;
   if (hipSetDevice(device) != hipSuccess) { delete ctx; return TFHE_HIP_ERR_RUNTIME; }
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+    ctx->num_cus = cus;
   std::vector<cplx> t;
   make_tables(t);
   if (hipMalloc((void**)&ctx->tables, t.size() * sizeof(cplx)) != hipSuccess ||
@@ -925,7 +950,7 @@ int tfhe_hip_bootstrap_noks_dev(tfhe_hip_ctx* ctx, int32_t mu, const int32_t* a,
   Scratch s;
   if (int rc = get_scratch(ctx, B, false, &s)) return rc;
   if (int rc = launch_prologue(ctx, a, b, nullptr, nullptr, 1, 0, 0, B, s.bara, s.barb)) return rc;
-  return launch_blind_rotate(ctx, s.bara, s.barb, mu, s.prev, nullptr, out_a, out_b, B);
+  return launch_blind_rotate(ctx, s.bara, s.barb, mu, nullptr, out_a, out_b, B);
 }
 
 int tfhe_hip_keyswitch_dev(tfhe_hip_ctx* ctx, const int32_t* a, const int32_t* b, int32_t* out_a,
@@ -944,7 +969,7 @@ int tfhe_hip_bootstrap_dev(tfhe_hip_ctx* ctx, int32_t mu, const int32_t* a, cons
   Scratch s;
   if (int rc = get_scratch(ctx, B, false, &s)) return rc;
   if (int rc = launch_prologue(ctx, a, b, nullptr, nullptr, 1, 0, 0, B, s.bara, s.barb)) return rc;
-  if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, mu, s.prev, nullptr, s.ea, s.eb, B)) return rc;
+  if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, mu, nullptr, s.ea, s.eb, B)) return rc;
   return launch_keyswitch(ctx, s.ea, s.eb, nullptr, nullptr, 0, out_a, out_b, var_out, B);
 }
 
@@ -963,16 +988,16 @@ int tfhe_hip_gate_dev(tfhe_hip_ctx* ctx, int gate, const int32_t* ca_a, const in
     gate_weights(TFHE_HIP_AND, &w1);
     gate_weights(TFHE_HIP_ANDNY, &w2);
     if (int rc = launch_prologue(ctx, ca_a, ca_b, cb_a, cb_b, w1.wa, w1.wb, w1.c, B, s.bara, s.barb)) return rc;
-    if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w1.mu, s.prev, nullptr, s.ea, s.eb, B)) return rc;
+    if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w1.mu, nullptr, s.ea, s.eb, B)) return rc;
     if (int rc = launch_prologue(ctx, ca_a, ca_b, cc_a, cc_b, w2.wa, w2.wb, w2.c, B, s.bara, s.barb)) return rc;
-    if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w2.mu, s.prev, nullptr, s.ea2, s.eb2, B)) return rc;
+    if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w2.mu, nullptr, s.ea2, s.eb2, B)) return rc;
     return launch_keyswitch(ctx, s.ea, s.eb, s.ea2, s.eb2, 1 << 29, out_a, out_b, var_out, B);
   }
   Weights w;
   if (!gate_weights(gate, &w)) return fail(ctx, TFHE_HIP_ERR_ARG, "unknown gate id");
   if (int rc = get_scratch(ctx, B, false, &s)) return rc;
   if (int rc = launch_prologue(ctx, ca_a, ca_b, cb_a, cb_b, w.wa, w.wb, w.c, B, s.bara, s.barb)) return rc;
-  if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w.mu, s.prev, nullptr, s.ea, s.eb, B)) return rc;
+  if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w.mu, nullptr, s.ea, s.eb, B)) return rc;
   return launch_keyswitch(ctx, s.ea, s.eb, nullptr, nullptr, 0, out_a, out_b, var_out, B);
 }
 
@@ -1114,9 +1139,8 @@ int tfhe_hip_blind_rotate(tfhe_hip_ctx* ctx, int32_t* acc, const int32_t* bara, 
   if (!acc || !bara) return fail(ctx, TFHE_HIP_ERR_ARG, "pointer is NULL");
   const size_t bytes = B * 3 * kN * sizeof(int32_t);
   STAGE_IN(dacc, acc, bytes) STAGE_IN(dbara, bara, B * ctx->P.n * 4)
-  STAGE_OUT(dprev, B * 2 * kN * sizeof(int32_t))
-  if (int rc = launch_blind_rotate(ctx, (int32_t*)dbara.p, nullptr, 0, (int32_t*)dprev.p,
-                                   (int32_t*)dacc.p, nullptr, nullptr, B)) return rc;
+  if (int rc = launch_blind_rotate(ctx, (int32_t*)dbara.p, nullptr, 0, (int32_t*)dacc.p, nullptr,
+                                   nullptr, B)) return rc;
   COPY_BACK(acc, dacc, bytes)
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return 0;

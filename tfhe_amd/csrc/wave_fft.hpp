@@ -11,6 +11,10 @@
 //   32 x 32 transpose between lanes and registers        (through LDS, swizzled)
 //   32-point DFT over the registers again
 //
+// Real and imaginary parts are transposed one after the other through the same
+// 8 KiB tile, which halves the exchange area (the other half of a wavefront's
+// LDS share holds per-ciphertext state of the caller).
+//
 // No workgroup barrier is used anywhere: every exchange is between lanes of
 // the same wavefront, whose LDS operations execute in program order.
 //
@@ -30,8 +34,10 @@
 namespace wfft {
 
 constexpr int kN = 1024;           // polynomial size
-constexpr int kHalfBytes = 16384;  // one 32x32 complex f64 tile
-constexpr int kWaveBytes = 32768;  // exchange area of one wavefront (two halves)
+constexpr int kHalfBytes = 8192;       // one 32x32 f64 tile (real OR imaginary parts of a half-wave)
+constexpr int kExchangeBytes = 16384;  // exchange area of one wavefront (two halves)
+constexpr int kStateBytes = 16384;     // caller's per-wavefront state behind the exchange area
+constexpr int kWaveBytes = kExchangeBytes + kStateBytes;
 
 struct alignas(16) cplx {
   double x, y;
@@ -208,41 +214,56 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ cplx lds_load(const char* base, int byte_off) {
-  return *reinterpret_cast<const cplx*>(base + byte_off);
+__device__ __forceinline__ double lds_load_f64(const char* base, int byte_off) {
+  return *reinterpret_cast<const double*>(base + byte_off);
 }
-__device__ __forceinline__ void lds_store(char* base, int byte_off, double x, double y) {
-  cplx v; v.x = x; v.y = y;
-  *reinterpret_cast<cplx*>(base + byte_off) = v;
+__device__ __forceinline__ void lds_store_f64(char* base, int byte_off, double x) {
+  *reinterpret_cast<double*>(base + byte_off) = x;
 }
+struct alignas(16) f64x2 {
+  double a, b;
+};
 
-// 32 x 32 transpose of one half-wave through its 16 KiB tile.  Element (row,
-// col) sits at row*512 + ((col ^ row) & 31)*16: both the row-wise stores and
-// the column-wise loads are bank-conflict free.  The store half is issued
-// element by element by the caller (fused with the twiddle multiplication, so
-// that the LDS store path works while the vector ALU does); transpose_load
-// fetches the columns.
+// 32 x 32 transpose of one f64 per (lane, register) of a half-wave through its
+// 8 KiB tile.  Element (row, col) sits at
+//   row*256 + (((col >> 1) ^ (row & 15)) * 2 + (col & 1)) * 8 :
+// 16-byte granules hold two adjacent columns of a row and are XOR-swizzled, so
+// the row-wise 8-byte stores and the column-wise 16-byte loads (two columns per
+// instruction) are both bank-conflict free.  The stores are issued element by
+// element by the caller (fused with the twiddle multiplication, so that the
+// LDS store path works while the vector ALU does).
 template <int ROW>
-__device__ __forceinline__ void transpose_store(char* tile, int q, double x, double y) {
-  lds_store(tile, ROW * 512 + ((q ^ ROW) & 31) * 16, x, y);
+__device__ __forceinline__ void transpose_store(char* tile, int q, double x) {
+  lds_store_f64(tile, ROW * 256 + (((q >> 1) ^ (ROW & 15)) << 4) + ((q & 1) << 3), x);
 }
 // OUT_BR: register p receives column index br5(p) (else p).
-// PAIR16: fetch in the order 0, 16, 1, 17, ... (the operand pairs of the first
-//         decimation-in-frequency stage) instead of 0, 1, 2, ...; LDS returns
-//         data in issue order, so arithmetic can start after two loads.
+// PAIR16: fetch in the order (0,1), (16,17), (2,3), (18,19), ... (operands of
+//         the first decimation-in-frequency stage) instead of ascending; LDS
+//         returns data in issue order, so arithmetic can start after two loads.
 template <bool OUT_BR, bool PAIR16>
-__device__ __forceinline__ void transpose_load(double (&re)[32], double (&im)[32], const char* tile,
-                                               int q) {
+__device__ __forceinline__ void transpose_load(double (&v)[32], const char* tile, int q) {
   wave_lds_fence();
-  static_for<0, 32>([&](auto ic) WFFT_INLINE {
+  const char* row = tile + q * 256;
+  const int qs = (q & 15) << 4;
+  static_for<0, 16>([&](auto ic) WFFT_INLINE {
     constexpr int i = decltype(ic)::value;
-    constexpr int p = PAIR16 ? ((i >> 1) + 16 * (i & 1)) : i;
-    constexpr int col = OUT_BR ? br5(p) : p;
-    const cplx v = lds_load(tile, q * 512 + ((col ^ q) & 31) * 16);
-    re[p] = v.x;
-    im[p] = v.y;
+    constexpr int cp = PAIR16 ? ((i >> 1) + 8 * (i & 1)) : i;     // column pair (2cp, 2cp+1)
+    const f64x2 w = *reinterpret_cast<const f64x2*>(row + ((cp << 4) ^ qs));
+    constexpr int p0 = OUT_BR ? br5(2 * cp) : 2 * cp;
+    constexpr int p1 = OUT_BR ? br5(2 * cp + 1) : 2 * cp + 1;
+    v[p0] = w.a;
+    v[p1] = w.b;
   });
   wave_lds_fence();
+}
+// Sends the 32 registers of v through the tile: v[p] is stored to row ROWOF(p).
+template <bool ROW_BR, bool OUT_BR, bool PAIR16>
+__device__ __forceinline__ void transpose_f64(double (&v)[32], char* tile, int q) {
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
+    constexpr int p = decltype(ic)::value;
+    transpose_store<ROW_BR ? br5(p) : p>(tile, q, v[p]);
+  });
+  transpose_load<OUT_BR, PAIR16>(v, tile, q);
 }
 
 // Forward 1024-point DFT of one half-wave.  natural in, S-layout out.
@@ -250,6 +271,9 @@ __device__ __forceinline__ void transpose_load(double (&re)[32], double (&im)[32
 __device__ __forceinline__ void fft1024_fwd(double (&re)[32], double (&im)[32], char* tile,
                                             const cplx* tE, int q) {
   dif32<false>(re, im);
+  // twiddle; the real parts leave for the tile at once, the imaginary parts
+  // follow when the real parts have come back (same tile, program order).
+  wave_lds_fence();
   pipelined_for32<4, cplx>(
       [&](auto ic) WFFT_INLINE { return tE[br5(decltype(ic)::value) * 32 + q]; },
       [&](auto ic, const cplx& w) WFFT_INLINE {
@@ -261,9 +285,11 @@ __device__ __forceinline__ void fft1024_fwd(double (&re)[32], double (&im)[32], 
           xi = xr * w.y + xi * w.x;
           xr = yr;
         }
-        transpose_store<kb>(tile, q, xr, xi);
+        im[p] = xi;
+        transpose_store<kb>(tile, q, xr);
       });
-  transpose_load<false, true>(re, im, tile, q);
+  transpose_load<false, true>(re, tile, q);
+  transpose_f64<true, false, true>(im, tile, q);
   dif32<false>(re, im);
 }
 
@@ -271,6 +297,7 @@ __device__ __forceinline__ void fft1024_fwd(double (&re)[32], double (&im)[32], 
 __device__ __forceinline__ void fft1024_inv(double (&re)[32], double (&im)[32], char* tile,
                                             const cplx* tE, int q) {
   dit32<true>(re, im);
+  wave_lds_fence();
   pipelined_for32<4, cplx>(
       [&](auto ic) WFFT_INLINE { return tE[decltype(ic)::value * 32 + q]; },
       [&](auto ic, const cplx& w) WFFT_INLINE {
@@ -281,9 +308,11 @@ __device__ __forceinline__ void fft1024_inv(double (&re)[32], double (&im)[32], 
           xi = xi * w.x - xr * w.y;
           xr = yr;
         }
-        transpose_store<kb>(tile, q, xr, xi);
+        im[kb] = xi;
+        transpose_store<kb>(tile, q, xr);
       });
-  transpose_load<true, false>(re, im, tile, q);
+  transpose_load<true, false>(re, tile, q);
+  transpose_f64<false, true, false>(im, tile, q);
   dit32<true>(re, im);
 }
 
@@ -363,30 +392,49 @@ __device__ __forceinline__ void inv2048_first_half(double (&re)[32], double (&im
   });
 }
 
-// Mirror exchange: on entry (re, im) is a spectrum C in fwd2048's layout; on
-// exit (mr, mi) holds conj(C[-k mod 2048]) at the position of bin k.
-__device__ __forceinline__ void mirror2048(const double (&re)[32], const double (&im)[32],
-                                           double (&mr)[32], double (&mi)[32], char* wave_tiles,
-                                           int q, int h) {
+// Mirror exchange of one f64 per bin.  A spectrum in fwd2048's layout has bin
+// k = 2*(q + 32*br5(p)) + h in lane (h, q), register p; its mirror image
+// -k mod 2048 lives in the same half, at lane q2 = (32 - q) & 31 (h = 0) or
+// 31 - q (h = 1) and register 31 - p, except for lane 0 of half E where the
+// register is br5((32 - br5(p)) & 31).  mirror_store writes v to the tile,
+// mirror_load<P> then returns the value of the mirror bin of register P.
+__device__ __forceinline__ void mirror_store(const double (&v)[32], char* wave_tiles, int q, int h) {
   char* tile = wave_tiles + h * kHalfBytes;
   wave_lds_fence();
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int p = decltype(ic)::value;
-    lds_store(tile, p * 512 + q * 16, re[p], im[p]);
+    lds_store_f64(tile, p * 256 + q * 8, v[p]);
   });
   wave_lds_fence();
-  // even bins: m = q + 32 ka -> (1024 - m) mod 1024; odd bins: m -> 1023 - m.
+}
+struct MirrorLane {
+  const char* base;   // tile + partner lane offset
+  bool wrap;          // lane 0 of half E: ka -> -ka mod 32 instead of 31 - ka
+};
+__device__ __forceinline__ MirrorLane mirror_lane(const char* wave_tiles, int q, int h) {
+  MirrorLane m;
   const int q2 = h ? (31 - q) : ((32 - q) & 31);
-  const bool wrap = (h == 0) && (q == 0);
-  static_for<0, 32>([&](auto ic) WFFT_INLINE {
-    constexpr int p = decltype(ic)::value;
-    constexpr int p_same = 31 - p;                      // br5(31 - ka) = 31 - br5(ka)
-    constexpr int p_wrap = br5((32 - br5(p)) & 31);     // lane 0 of half E: ka -> -ka mod 32
-    const int p2 = wrap ? p_wrap : p_same;
-    const cplx v = lds_load(tile, p2 * 512 + q2 * 16);
-    mr[p] = v.x;
-    mi[p] = -v.y;
-  });
+  m.base = wave_tiles + h * kHalfBytes + q2 * 8;
+  m.wrap = (h == 0) && (q == 0);
+  return m;
+}
+template <int P>
+__device__ __forceinline__ double mirror_load(const MirrorLane& m) {
+  constexpr int p_same = 31 - P;
+  constexpr int p_wrap = br5((32 - br5(P)) & 31);
+  return lds_load_f64(m.base, (m.wrap ? p_wrap : p_same) * 256);
+}
+
+// On entry (re, im) is a spectrum C in fwd2048's layout; on exit (mr, mi)
+// holds conj(C[-k mod 2048]) at the position of bin k.
+__device__ __forceinline__ void mirror2048(const double (&re)[32], const double (&im)[32],
+                                           double (&mr)[32], double (&mi)[32], char* wave_tiles,
+                                           int q, int h) {
+  const MirrorLane ml = mirror_lane(wave_tiles, q, h);
+  mirror_store(re, wave_tiles, q, h);
+  static_for<0, 32>([&](auto ic) WFFT_INLINE { mr[decltype(ic)::value] = mirror_load<decltype(ic)::value>(ml); });
+  mirror_store(im, wave_tiles, q, h);
+  static_for<0, 32>([&](auto ic) WFFT_INLINE { mi[decltype(ic)::value] = -mirror_load<decltype(ic)::value>(ml); });
   wave_lds_fence();
 }
 
@@ -416,41 +464,6 @@ __device__ __forceinline__ void agpr_put_f64(double v, unsigned& lo, unsigned& h
 __device__ __forceinline__ double agpr_get_f64(unsigned lo, unsigned hi) {
   const unsigned long long u = ((unsigned long long)agpr_get(hi) << 32) | agpr_get(lo);
   return __longlong_as_double((long long)u);
-}
-
-// The mirror exchange in two steps, for callers that consume the mirrored
-// spectrum element by element: mirror_store writes C to the tile, then
-// mirror_load<P> returns conj(C[-k mod 2048]) for the bin k held in register P.
-__device__ __forceinline__ void mirror_store(const double (&re)[32], const double (&im)[32],
-                                             char* wave_tiles, int q, int h) {
-  char* tile = wave_tiles + h * kHalfBytes;
-  wave_lds_fence();
-  static_for<0, 32>([&](auto ic) WFFT_INLINE {
-    constexpr int p = decltype(ic)::value;
-    lds_store(tile, p * 512 + q * 16, re[p], im[p]);
-  });
-  wave_lds_fence();
-}
-struct MirrorLane {
-  const char* base;   // tile + partner lane offset
-  bool wrap;          // lane 0 of half E: ka -> -ka mod 32 instead of 31 - ka
-};
-__device__ __forceinline__ MirrorLane mirror_lane(const char* wave_tiles, int q, int h) {
-  MirrorLane m;
-  const int q2 = h ? (31 - q) : ((32 - q) & 31);
-  m.base = wave_tiles + h * kHalfBytes + q2 * 16;
-  m.wrap = (h == 0) && (q == 0);
-  return m;
-}
-template <int P>
-__device__ __forceinline__ cplx mirror_load(const MirrorLane& m) {
-  constexpr int p_same = 31 - P;
-  constexpr int p_wrap = br5((32 - br5(P)) & 31);
-  const cplx v = lds_load(m.base, (m.wrap ? p_wrap : p_same) * 512);
-  cplx r;
-  r.x = v.x;
-  r.y = -v.y;
-  return r;
 }
 
 // Rust `f64::round() as i32`: round half away from zero, saturate, NaN -> 0.
