@@ -81,11 +81,23 @@ constexpr int kPrevOff = wfft::kExchangeBytes;
 constexpr int kTtOff = wfft::kExchangeBytes + 2 * kN * 4;
 static_assert(kTtOff + 2 * kN * 4 <= wfft::kWaveBytes, "per-wavefront LDS share");
 
+// The sample to decompose is stored XORed with tt_mask: digit p of
+// src/tgsw.rs:299-328, ((c + 0x80000000) >> decal_p) & (Bg - 1)) - Bg/2, is then
+// the sign-extended bit field [decal_p, decal_p + bg_bit) of the stored word
+// (adding 2^31 flips bit 31; subtracting Bg/2 from a field equals flipping its
+// top bit and sign-extending; for p = 0 the two flips of bit 31 cancel).
+template <int L, int BGBIT>
+constexpr uint32_t tt_mask() {
+  uint32_t m = 0;
+  for (int p = 1; p < L; p++) m |= 1u << (31 - p * BGBIT);
+  return m;
+}
+
 // ---------------------------------------------------------------------------
 // External product core (src/tgsw.rs:229-264, src/tlwe.rs:149-157,
 // src/numerics.rs:138-155).
 //
-// tt (LDS) : the TLWE sample being decomposed, [N][2] int32.
+// tt (LDS) : the TLWE sample being decomposed, [N][2] int32, XORed with tt_mask.
 // acc_a[r] : lane (h, q) accumulates coefficient t = q + 32 r of result
 //            polynomial u = h; handles of values parked in accumulation
 //            registers (wfft::agpr_*).  Every product is rounded and saturated
@@ -99,8 +111,6 @@ __device__ __forceinline__ void extprod_accumulate(unsigned (&acc_a)[32], const 
   const int h = lane >> 5, q = lane & 31;
   char* wave_tiles = wave_lds;
   const char* tt = wave_lds + kTtOff + q * 8;
-  constexpr int32_t kHalfBg = 1 << (BGBIT - 1);
-  constexpr int32_t kMask = (1 << BGBIT) - 1;
   auto accumulate = [&](auto rc, double v) WFFT_INLINE {
     constexpr int r = decltype(rc)::value;
     acc_a[r] = wfft::agpr_put((unsigned)wadd((int32_t)wfft::agpr_get(acc_a[r]), wfft::round_sat_i32(v)));
@@ -116,8 +126,8 @@ __device__ __forceinline__ void extprod_accumulate(unsigned (&acc_a)[32], const 
     static_for<0, 32>([&](auto ic) WFFT_INLINE {
       constexpr int r = decltype(ic)::value;
       const int2 t = *reinterpret_cast<const int2*>(tt + r * 256);
-      re[r] = (double)((((wadd(t.x, (int32_t)0x80000000u)) >> decal) & kMask) - kHalfBg);
-      im[r] = (double)((((wadd(t.y, (int32_t)0x80000000u)) >> decal) & kMask) - kHalfBg);
+      re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t.x, decal, BGBIT);
+      im[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t.y, decal, BGBIT);
     });
     // C = FFT(c); the two real spectra are separated with the mirror:
     // D_0 = C + Ct, D_1 = -i (C - Ct) with Ct[k] = conj(C[-k]); the factor 1/2
@@ -178,7 +188,7 @@ __device__ __forceinline__ void extprod_accumulate(unsigned (&acc_a)[32], const 
       });
     }
     TFHE_STAMP(st, 4);
-    wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate);
+    wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate, []() WFFT_INLINE {});
     TFHE_STAMP(st, 5);
     {
       // Z_1 = D_1 * key_1 as D_1 comes back from the accumulation registers.
@@ -193,7 +203,7 @@ __device__ __forceinline__ void extprod_accumulate(unsigned (&acc_a)[32], const 
       });
     }
     TFHE_STAMP(st, 6);
-    wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate);
+    wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate, []() WFFT_INLINE {});
     TFHE_STAMP(st, 7);
   }
 }
@@ -201,19 +211,25 @@ __device__ __forceinline__ void extprod_accumulate(unsigned (&acc_a)[32], const 
 // t = X^abar (prev + acc) - acc for polynomials 0 and 1
 // (src/bootstrapping.rs:136-146, src/polynomial.rs:281-313), then prev <- acc.
 // acc is parked in accumulation registers (lane (h, q) register r = polynomial
-// h, coefficient q + 32 r); prev and t live in the wavefront's LDS share; the
+// h, coefficient q + 32 r); prev and t (XORed with mask, see tt_mask) live in
+// the wavefront's LDS share; the
 // sum prev + acc is staged through the exchange area for the rotation.
 __device__ __forceinline__ void rotate_diff(const unsigned (&acc_a)[32], int abar, char* wave_lds,
-                                            int lane) {
+                                            int lane, uint32_t mask) {
   const int h = lane >> 5, q = lane & 31;
   int32_t* S = reinterpret_cast<int32_t*>(wave_lds) + h * kN;              // [2][N] prev + acc
   int32_t* pv = reinterpret_cast<int32_t*>(wave_lds + kPrevOff) + h * kN + q;
   int32_t* tt = reinterpret_cast<int32_t*>(wave_lds + kTtOff) + 2 * q + h;
+  // Loads and stores are issued in separate batches: the compiler cannot tell
+  // the LDS areas apart and would otherwise serialise load, wait, store.
+  int32_t v[32];
+  wfft::wave_lds_fence();
+  static_for<0, 32>([&](auto ic) WFFT_INLINE { v[decltype(ic)::value] = pv[32 * decltype(ic)::value]; });
   wfft::wave_lds_fence();
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     const int32_t a = (int32_t)wfft::agpr_get(acc_a[r]);
-    S[q + 32 * r] = wadd(pv[32 * r], a);
+    S[q + 32 * r] = wadd(v[r], a);
     pv[32 * r] = a;
   });
   wfft::wave_lds_fence();
@@ -223,11 +239,14 @@ __device__ __forceinline__ void rotate_diff(const unsigned (&acc_a)[32], int aba
   const int wrap = abar > 0 ? base : (abar == -kN ? -(1 << 20) : (1 << 20));
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
-    const int src = (base + 32 * r) & (kN - 1);
+    v[r] = S[(base + 32 * r) & (kN - 1)];
+  });
+  wfft::wave_lds_fence();
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
+    constexpr int r = decltype(ic)::value;
     const bool neg = wrap < -32 * r;
-    int32_t v = S[src];
-    v = neg ? wneg(v) : v;
-    tt[64 * r] = wsub(v, (int32_t)wfft::agpr_get(acc_a[r]));
+    const int32_t x = neg ? wneg(v[r]) : v[r];
+    tt[64 * r] = (int32_t)((uint32_t)wsub(x, (int32_t)wfft::agpr_get(acc_a[r])) ^ mask);
   });
   wfft::wave_lds_fence();
 }
@@ -295,7 +314,7 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
     int ln = lane;
     asm volatile("" : "+v"(ln));
     TFHE_STAMP(st, 8);
-    rotate_diff(acc_a, abar, wave_tiles, ln);                  // also prev <- acc
+    rotate_diff(acc_a, abar, wave_tiles, ln, tt_mask<L, BGBIT>());   // also prev <- acc
     TFHE_STAMP(st, 0);
     extprod_accumulate<L, BGBIT>(acc_a, args.bkfft + (size_t)i * L * 2 * 2048, wave_tiles, tE, tw, ln,
                                  st);
@@ -352,7 +371,7 @@ __global__ __launch_bounds__(kBlock, 1) void extprod_kernel(const int32_t* __res
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     reinterpret_cast<int32_t*>(wave_tiles + kTtOff)[2 * (q + 32 * r) + h] =
-        t[((size_t)b * 3 + h) * kN + q + 32 * r];
+        (int32_t)((uint32_t)t[((size_t)b * 3 + h) * kN + q + 32 * r] ^ tt_mask<L, BGBIT>());
     acc_a[r] = wfft::agpr_put(0u);
   });
   StampCtx st;

@@ -377,11 +377,15 @@ __device__ __forceinline__ void swap_halves(double& a, double& b) {
 // spectrum in the layout fwd2048 produces.  On exit lane (h, q), register r
 // holds, for t = q + 32 r: the REAL part of x[t] when h == 0, the IMAGINARY
 // part when h == 1; each value is handed to sink(integral_constant<r>, value).
-template <class Sink>
+// mid() runs between the transform proper and the element-wise tail (a place
+// with few live registers, for the caller to start loads of its next phase).
+template <class Sink, class Mid>
 __device__ __forceinline__ void inv2048_first_half(double (&re)[32], double (&im)[32],
                                                    char* wave_tiles, const cplx* tE,
-                                                   const cplx* tw, int q, int h, Sink&& sink) {
+                                                   const cplx* tw, int q, int h, Sink&& sink,
+                                                   Mid&& mid) {
   fft1024_inv(re, im, wave_tiles + h * kHalfBytes, tE, q);
+  mid();
   twist_odd_half<true>(re, im, tw, q, h);
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
