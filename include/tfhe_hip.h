@@ -64,6 +64,16 @@ int tfhe_hip_set_stream(tfhe_hip_ctx* ctx, void* hip_stream);
 /* Waits for the context's stream. */
 int tfhe_hip_synchronize(tfhe_hip_ctx* ctx);
 
+/* How tfhe_blind_rotate (src/bootstrapping.rs:109-134) is mapped to the GPU.
+ * BATCH: one ciphertext per wavefront, persistent workgroups (throughput form).
+ * SPLIT: one ciphertext per workgroup, one wavefront per (decomposition level,
+ *        key column) pair of tgsw_extern_mul_to_tlwe (src/tgsw.rs:229-264); a
+ *        third of the latency, 4/3 of the arithmetic.
+ * AUTO (default): SPLIT while the batch has at most two ciphertexts per
+ *        compute unit, BATCH above.  Results are identical in every mode. */
+enum { TFHE_HIP_BR_AUTO = 0, TFHE_HIP_BR_BATCH = 1, TFHE_HIP_BR_SPLIT = 2 };
+int tfhe_hip_set_blind_rotate_mode(tfhe_hip_ctx* ctx, int mode);
+
 /* Per-kernel timing with HIP events on the context's stream.  While enabled,
  * every launch of the gate-prologue, blind-rotate and key-switch kernels is
  * bracketed by two events.  tfhe_hip_profile_read waits for the stream and

@@ -15,10 +15,13 @@ pytestmark = pytest.mark.gpu
 SHAPES = {"l2": (2, 10), "l3": (3, 7)}
 
 
-@pytest.fixture(scope="module")
-def eng():
+@pytest.fixture(scope="module", params=["batch", "split"])
+def eng(request):
+    """Every test runs against both mappings of the blind rotation (one
+    ciphertext per wavefront / per workgroup); results must be identical."""
     import tfhe_amd
     e = tfhe_amd.Engine(0)
+    e.set_blind_rotate_mode(request.param)
     yield e
     e.close()
 
@@ -217,6 +220,36 @@ def test_bootstrap_full_size_synthetic_keys(eng, level, B):
         wa, wb, wv, _ = orc.bootstrap(P, K["bk"], K["ks_a"], K["ks_b"], mu, a[i], b[i], None,
                                       K["ks_var"], orc.MUL_EXACT)
         assert (oa[i] == wa).all() and ob[i] == wb and var[i] == wv, i
+
+
+@pytest.mark.parametrize("level", [80, 128])
+def test_blind_rotate_mappings_agree_at_full_size(level):
+    """Size-independent property at the bench's parameters: the throughput and
+    the low-latency mapping return the same bits on a batch that spans several
+    rounds of persistent workgroups (and the automatic choice equals both)."""
+    import tfhe_amd
+    P = orc.params(level)
+    K = orc.generate_synthetic_keys(P, 90 + level)
+    B = 1030
+    ca = (orc.uniform_i32(91, (B, P.n)), orc.uniform_i32(92, (B,)))
+    cb = (orc.uniform_i32(93, (B, P.n)), orc.uniform_i32(94, (B,)))
+    out = {}
+    e = tfhe_amd.Engine(0)
+    try:
+        _load(e, P, K)
+        for mode in ("batch", "split", "auto"):
+            e.set_blind_rotate_mode(mode)
+            out[mode] = e.gate("xor", ca, cb, want_var=True)
+    finally:
+        e.close()
+    for mode in ("split", "auto"):
+        for x, y in zip(out["batch"], out[mode]):
+            assert (x == y).all(), mode
+    # and two ciphertexts of the batch against the oracle
+    for i in (0, B - 1):
+        wa, wb, wv = orc.gate(P, "xor", K, (ca[0][i], ca[1][i], 0.0), (cb[0][i], cb[1][i], 0.0), None,
+                              orc.MUL_EXACT)
+        assert (out["batch"][0][i] == wa).all() and out["batch"][1][i] == wb and out["batch"][2][i] == wv
 
 
 def test_errors_are_reported_not_thrown(eng):

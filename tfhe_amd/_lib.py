@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TFHE_HIP_LIB") or os.path.join(HERE, "libtfhe_hip.so")
 
 SYMBOLS = [
-    "tfhe_hip_create", "tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_set_stream",
+    "tfhe_hip_create", "tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_set_stream", "tfhe_hip_set_blind_rotate_mode",
     "tfhe_hip_synchronize", "tfhe_hip_load_keys", "tfhe_hip_key_blob_sizes",
     "tfhe_hip_export_keys_dev", "tfhe_hip_import_keys_dev", "tfhe_hip_bootstrap",
     "tfhe_hip_bootstrap_dev", "tfhe_hip_bootstrap_noks", "tfhe_hip_bootstrap_noks_dev",
@@ -47,6 +47,7 @@ def load():
     lib.tfhe_hip_last_error.restype = C.c_char_p
     lib.tfhe_hip_set_stream.argtypes = [vp, vp]
     lib.tfhe_hip_synchronize.argtypes = [vp]
+    lib.tfhe_hip_set_blind_rotate_mode.argtypes = [vp, C.c_int]
     lib.tfhe_hip_load_keys.argtypes = [vp, PP, i32p, i32p, i32p, f64p]
     lib.tfhe_hip_key_blob_sizes.argtypes = [PP, C.POINTER(sz), C.POINTER(sz)]
     lib.tfhe_hip_export_keys_dev.argtypes = [vp, vp, vp]

@@ -104,108 +104,120 @@ constexpr uint32_t tt_mask() {
 //            to i32 on its own before the wrapping add, as the reference does.
 // bk       : FFT-domain key of this iteration, [l][2][32][64] cplx.
 // ---------------------------------------------------------------------------
+// One decomposition level of the external product: digits of level p of both
+// polynomials, one forward transform, the two real spectra D_0 and D_1, their
+// products with the two key columns of the level, two inverse transforms; each
+// rounded coefficient is handed to accumulate(integral_constant<r>, value) by
+// lane (h, q) for coefficient t = q + 32 r of result polynomial u = h.
+// tt: this lane's base (+ 8 q) into the [N][2] int32 sample (XORed with tt_mask).
+// bk_level: [2][32][64] cplx, the two key columns of the level.
+template <int BGBIT, class Acc>
+__device__ __forceinline__ void level_product(int p, const char* tt, const cplx* __restrict__ bk_level,
+                                              char* wave_tiles, const cplx* tE, const cplx* tw,
+                                              int lane, Acc&& accumulate, StampCtx& st) {
+  const int h = lane >> 5, q = lane & 31;
+  double re[32], im[32];
+  unsigned hold[128];      // parked spectrum D_1
+  // gadget decomposition, src/tgsw.rs:299-328 (offset 0x80000000, tgsw.rs:50-52);
+  // every lane needs the digits of both polynomials: c = d_{p,0} + i d_{p,1}.
+  const int decal = 32 - (p + 1) * BGBIT;
+  wfft::wave_lds_fence();
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
+    constexpr int r = decltype(ic)::value;
+    const int2 t = *reinterpret_cast<const int2*>(tt + r * 256);
+    re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t.x, decal, BGBIT);
+    im[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t.y, decal, BGBIT);
+  });
+  // C = FFT(c); the two real spectra are separated with the mirror:
+  // D_0 = C + Ct, D_1 = -i (C - Ct) with Ct[k] = conj(C[-k]); the factor 1/2
+  // is folded into the key.
+  TFHE_STAMP(st, 1);
+  wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+  TFHE_STAMP(st, 2);
+  const cplx* b0 = bk_level + lane;
+  const cplx* b1 = bk_level + 2048 + lane;
+  auto load_k0 = [&](auto ic) WFFT_INLINE { return b0[decltype(ic)::value * 64]; };
+  auto load_k1 = [&](auto ic) WFFT_INLINE { return b1[decltype(ic)::value * 64]; };
+  {
+    // Z_0 = D_0 * key_0 in place; D_1 is parked.  The first loads of key
+    // column 0 are issued before the mirror passes.  Real parts go through
+    // the tile first, then the imaginary parts.
+    wfft::Pipe32<4, 3, cplx> k0p;
+    k0p.prologue(load_k0);
+    const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
+    wfft::mirror_store(re, wave_tiles, q, h);
+    TFHE_STAMP(st, 3);
+    wfft::pipelined_for32<4, double>(
+        [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
+        [&](auto ic, const double& ctx) WFFT_INLINE {
+          constexpr int s = decltype(ic)::value;
+          const double c = re[s];
+          re[s] = c + ctx;                                            // Re D_0
+          wfft::agpr_put_f64(ctx - c, hold[4 * s + 2], hold[4 * s + 3]);   // Im D_1
+        });
+    wfft::mirror_store(im, wave_tiles, q, h);
+    auto load_my = [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); };
+    wfft::Pipe32<4, 1, double> myp;
+    myp.prologue(load_my);
+    static_for<0, 8>([&](auto gc) WFFT_INLINE {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (g + 3 < 8) {
+        static_for<0, 4>([&](auto ic) WFFT_INLINE {
+          constexpr int e = decltype(ic)::value;
+          k0p.buf[(g + 3) % 4][e] = load_k0(std::integral_constant<int, (g + 3) * 4 + e>{});
+        });
+      }
+      if constexpr (g + 1 < 8) {
+        static_for<0, 4>([&](auto ic) WFFT_INLINE {
+          constexpr int e = decltype(ic)::value;
+          myp.buf[(g + 1) % 2][e] = load_my(std::integral_constant<int, (g + 1) * 4 + e>{});
+        });
+      }
+      static_for<0, 4>([&](auto ic) WFFT_INLINE {
+        constexpr int e = decltype(ic)::value;
+        constexpr int s = g * 4 + e;
+        const double my = myp.buf[g % 2][e];          // Im C[-k]; Ct = (.., -my)
+        const cplx ka = k0p.buf[g % 4][e];
+        const double d0r = re[s], d0i = im[s] - my;
+        wfft::agpr_put_f64(im[s] + my, hold[4 * s + 0], hold[4 * s + 1]);   // Re D_1
+        re[s] = d0r * ka.x - d0i * ka.y;
+        im[s] = d0r * ka.y + d0i * ka.x;
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+  TFHE_STAMP(st, 4);
+  wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate, []() WFFT_INLINE {});
+  TFHE_STAMP(st, 5);
+  {
+    // Z_1 = D_1 * key_1 as D_1 comes back from the accumulation registers.
+    wfft::Pipe32<4, 3, cplx> k1p;
+    k1p.prologue(load_k1);
+    k1p.run(load_k1, [&](auto ic, const cplx& kb) WFFT_INLINE {
+      constexpr int s = decltype(ic)::value;
+      const double d1r = wfft::agpr_get_f64(hold[4 * s + 0], hold[4 * s + 1]);
+      const double d1i = wfft::agpr_get_f64(hold[4 * s + 2], hold[4 * s + 3]);
+      re[s] = d1r * kb.x - d1i * kb.y;
+      im[s] = d1r * kb.y + d1i * kb.x;
+    });
+  }
+  TFHE_STAMP(st, 6);
+  wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate, []() WFFT_INLINE {});
+  TFHE_STAMP(st, 7);
+}
+
 template <int L, int BGBIT>
 __device__ __forceinline__ void extprod_accumulate(unsigned (&acc_a)[32], const cplx* __restrict__ bk,
                                                    char* wave_lds, const cplx* tE, const cplx* tw,
                                                    int lane, StampCtx& st) {
-  const int h = lane >> 5, q = lane & 31;
-  char* wave_tiles = wave_lds;
-  const char* tt = wave_lds + kTtOff + q * 8;
+  const char* tt = wave_lds + kTtOff + (lane & 31) * 8;
   auto accumulate = [&](auto rc, double v) WFFT_INLINE {
     constexpr int r = decltype(rc)::value;
     acc_a[r] = wfft::agpr_put((unsigned)wadd((int32_t)wfft::agpr_get(acc_a[r]), wfft::round_sat_i32(v)));
   };
 #pragma unroll 1
-  for (int p = 0; p < L; p++) {
-    double re[32], im[32];
-    unsigned hold[128];      // parked spectrum D_1
-    // gadget decomposition, src/tgsw.rs:299-328 (offset 0x80000000, tgsw.rs:50-52);
-    // every lane needs the digits of both polynomials: c = d_{p,0} + i d_{p,1}.
-    const int decal = 32 - (p + 1) * BGBIT;
-    wfft::wave_lds_fence();
-    static_for<0, 32>([&](auto ic) WFFT_INLINE {
-      constexpr int r = decltype(ic)::value;
-      const int2 t = *reinterpret_cast<const int2*>(tt + r * 256);
-      re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t.x, decal, BGBIT);
-      im[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t.y, decal, BGBIT);
-    });
-    // C = FFT(c); the two real spectra are separated with the mirror:
-    // D_0 = C + Ct, D_1 = -i (C - Ct) with Ct[k] = conj(C[-k]); the factor 1/2
-    // is folded into the key.
-    TFHE_STAMP(st, 1);
-    wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
-    TFHE_STAMP(st, 2);
-    const cplx* b0 = bk + ((size_t)(p * 2 + 0) * 32) * 64 + lane;
-    const cplx* b1 = bk + ((size_t)(p * 2 + 1) * 32) * 64 + lane;
-    auto load_k0 = [&](auto ic) WFFT_INLINE { return b0[decltype(ic)::value * 64]; };
-    auto load_k1 = [&](auto ic) WFFT_INLINE { return b1[decltype(ic)::value * 64]; };
-    {
-      // Z_0 = D_0 * key_0 in place; D_1 is parked.  The first loads of key
-      // column 0 are issued before the mirror passes.  Real parts go through
-      // the tile first, then the imaginary parts.
-      wfft::Pipe32<4, 3, cplx> k0p;
-      k0p.prologue(load_k0);
-      const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
-      wfft::mirror_store(re, wave_tiles, q, h);
-      TFHE_STAMP(st, 3);
-      wfft::pipelined_for32<4, double>(
-          [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
-          [&](auto ic, const double& ctx) WFFT_INLINE {
-            constexpr int s = decltype(ic)::value;
-            const double c = re[s];
-            re[s] = c + ctx;                                            // Re D_0
-            wfft::agpr_put_f64(ctx - c, hold[4 * s + 2], hold[4 * s + 3]);   // Im D_1
-          });
-      wfft::mirror_store(im, wave_tiles, q, h);
-      auto load_my = [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); };
-      wfft::Pipe32<4, 1, double> myp;
-      myp.prologue(load_my);
-      static_for<0, 8>([&](auto gc) WFFT_INLINE {
-        constexpr int g = decltype(gc)::value;
-        if constexpr (g + 3 < 8) {
-          static_for<0, 4>([&](auto ic) WFFT_INLINE {
-            constexpr int e = decltype(ic)::value;
-            k0p.buf[(g + 3) % 4][e] = load_k0(std::integral_constant<int, (g + 3) * 4 + e>{});
-          });
-        }
-        if constexpr (g + 1 < 8) {
-          static_for<0, 4>([&](auto ic) WFFT_INLINE {
-            constexpr int e = decltype(ic)::value;
-            myp.buf[(g + 1) % 2][e] = load_my(std::integral_constant<int, (g + 1) * 4 + e>{});
-          });
-        }
-        static_for<0, 4>([&](auto ic) WFFT_INLINE {
-          constexpr int e = decltype(ic)::value;
-          constexpr int s = g * 4 + e;
-          const double my = myp.buf[g % 2][e];          // Im C[-k]; Ct = (.., -my)
-          const cplx ka = k0p.buf[g % 4][e];
-          const double d0r = re[s], d0i = im[s] - my;
-          wfft::agpr_put_f64(im[s] + my, hold[4 * s + 0], hold[4 * s + 1]);   // Re D_1
-          re[s] = d0r * ka.x - d0i * ka.y;
-          im[s] = d0r * ka.y + d0i * ka.x;
-        });
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    }
-    TFHE_STAMP(st, 4);
-    wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate, []() WFFT_INLINE {});
-    TFHE_STAMP(st, 5);
-    {
-      // Z_1 = D_1 * key_1 as D_1 comes back from the accumulation registers.
-      wfft::Pipe32<4, 3, cplx> k1p;
-      k1p.prologue(load_k1);
-      k1p.run(load_k1, [&](auto ic, const cplx& kb) WFFT_INLINE {
-        constexpr int s = decltype(ic)::value;
-        const double d1r = wfft::agpr_get_f64(hold[4 * s + 0], hold[4 * s + 1]);
-        const double d1i = wfft::agpr_get_f64(hold[4 * s + 2], hold[4 * s + 3]);
-        re[s] = d1r * kb.x - d1i * kb.y;
-        im[s] = d1r * kb.y + d1i * kb.x;
-      });
-    }
-    TFHE_STAMP(st, 6);
-    wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate, []() WFFT_INLINE {});
-    TFHE_STAMP(st, 7);
-  }
+  for (int p = 0; p < L; p++)
+    level_product<BGBIT>(p, tt, bk + (size_t)p * 2 * 2048, wave_lds, tE, tw, lane, accumulate, st);
 }
 
 // t = X^abar (prev + acc) - acc for polynomials 0 and 1
@@ -348,6 +360,168 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
       args.out_b[b] = barb >= 0 ? args.mu : wneg(args.mu);
     }
   }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Small batches: one WORKGROUP per ciphertext.  The (digit polynomial, key
+// column) pairs of an external product are independent until their rounded
+// results meet in the accumulator.  With CPW = 1 (columns per wavefront)
+// wavefront w = 2 p + j takes level p and key column j: digits of level p,
+// forward transform, the real spectrum D_j, product with key_{p,j}, inverse
+// transform; an iteration then costs one forward and one inverse transform per
+// wavefront instead of l and 2 l, at the price of computing each forward
+// transform twice.  With CPW = 2 wavefront w takes level w with both columns
+// (level_product).  Either way the rounded products are added (wrapping, in
+// LDS) into the shared accumulator.  This is the low-latency form, used when
+// the batch cannot fill the machine with one ciphertext per wavefront; l = 3
+// uses CPW = 2 because six wavefronts would have to share four SIMDs and half
+// the registers.
+//
+// LDS: per wavefront the FFT exchange area, then per workgroup prev [2][N],
+// acc [2][N], tt [N][2] (int32), then the twiddle tables.
+// ---------------------------------------------------------------------------
+template <int W>
+constexpr int split_lds_bytes() {
+  return W * wfft::kExchangeBytes + 3 * 2 * kN * 4 + kTableBytes;
+}
+
+template <int L, int BGBIT, bool HOOK, int CPW>
+__global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel(BlindRotateArgs args) {
+  constexpr int W = L * 2 / CPW;
+  static_assert(W <= 4, "one wavefront per SIMD");
+  __shared__ __attribute__((aligned(16))) char lds[split_lds_bytes<W>()];
+  char* shared = lds + W * wfft::kExchangeBytes;
+  int32_t* prevL = reinterpret_cast<int32_t*>(shared);
+  int32_t* accL = prevL + 2 * kN;
+  int32_t* ttL = accL + 2 * kN;
+  char* lds_tables = shared + 3 * 2 * kN * 4;
+  load_tables(lds_tables, args.tables);
+  const cplx* tE = reinterpret_cast<const cplx*>(lds_tables);
+  const cplx* tw = tE + 1024;
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, q = lane & 31;
+  const int p = CPW == 1 ? wave >> 1 : wave, j = wave & 1;
+  char* wave_tiles = lds + wave * wfft::kExchangeBytes;
+  const int b = blockIdx.x;
+  constexpr uint32_t kMaskTt = tt_mask<L, BGBIT>();
+  const int decal = 32 - (p + 1) * BGBIT;
+  StampCtx st;
+  // wrapping add of a rounded, saturated product (numerics.rs:138-155)
+  auto accumulate = [&](auto rc, double v) WFFT_INLINE {
+    constexpr int r = decltype(rc)::value;
+    atomicAdd(reinterpret_cast<unsigned*>(accL) + h * kN + q + 32 * r, (unsigned)wfft::round_sat_i32(v));
+  };
+
+  for (int x = threadIdx.x; x < 2 * kN; x += 64 * W) {
+    prevL[x] = 0;                                              // bootstrapping.rs:116-117
+    accL[x] = HOOK ? args.acc_io[(size_t)b * 3 * kN + x] : 0;
+  }
+
+  const int32_t* bara = args.bara + (size_t)b * args.n;
+  int abar64 = 0;
+#pragma unroll 1
+  for (int i = 0; i < args.n; i++) {
+    if ((i & 63) == 0) abar64 = (i + lane < args.n) ? bara[i + lane] : 0;
+    const int abar = __builtin_amdgcn_readlane(abar64, i & 63);
+    if (abar == 0) continue;                                   // bootstrapping.rs:122-126
+    __syncthreads();                                           // acc of the last iteration is complete
+    // t = X^abar (prev + acc) - acc, rows r = wave, wave + W, ... of each polynomial
+    // (src/bootstrapping.rs:136-146, src/polynomial.rs:281-313); then prev <- acc.
+    {
+      const int base = q - abar;
+      const int wrap = abar > 0 ? base : (abar == -kN ? -(1 << 20) : (1 << 20));
+      constexpr int kRows = (32 + W - 1) / W;
+      int32_t keep[kRows];
+      static_for<0, kRows>([&](auto ic) WFFT_INLINE {
+        constexpr int e = decltype(ic)::value;
+        const int r = wave + W * e;
+        if (r < 32) {
+          const int n = q + 32 * r;
+          const int src = (base + 32 * r) & (kN - 1);
+          const int32_t v = wadd(prevL[h * kN + src], accL[h * kN + src]);
+          const int32_t a = accL[h * kN + n];
+          const int32_t x = (wrap < -32 * r) ? wneg(v) : v;
+          ttL[2 * n + h] = (int32_t)((uint32_t)wsub(x, a) ^ kMaskTt);
+          keep[e] = a;
+        }
+      });
+      __syncthreads();                                         // tt complete, prev no longer read
+      static_for<0, kRows>([&](auto ic) WFFT_INLINE {
+        constexpr int e = decltype(ic)::value;
+        const int r = wave + W * e;
+        if (r < 32) prevL[h * kN + q + 32 * r] = keep[e];
+      });
+    }
+    const char* tt = reinterpret_cast<const char*>(ttL) + q * 8;
+    if constexpr (CPW == 2) {
+      level_product<BGBIT>(p, tt, args.bkfft + ((size_t)i * L + p) * 2 * 2048, wave_tiles, tE, tw, lane,
+                           accumulate, st);
+    } else {
+    // this wavefront's (level, column) product
+    double re[32], im[32];
+    static_for<0, 32>([&](auto ic) WFFT_INLINE {
+      constexpr int r = decltype(ic)::value;
+      const int2 t = *reinterpret_cast<const int2*>(tt + r * 256);
+      re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t.x, decal, BGBIT);
+      im[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t.y, decal, BGBIT);
+    });
+    wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+    const cplx* kcol = args.bkfft + ((size_t)i * L * 2 + (size_t)(p * 2 + j)) * 2048 + lane;
+    auto load_k = [&](auto ic) WFFT_INLINE { return kcol[decltype(ic)::value * 64]; };
+    wfft::Pipe32<4, 3, cplx> kp;
+    kp.prologue(load_k);
+    // D_0 = C + Ct (column 0) or D_1 = -i (C - Ct) (column 1), Ct[k] = conj(C[-k]):
+    //   j = 0: Re = re + cx, Im = im - my;   j = 1: Re = im + my, Im = cx - re
+    // with cx, my the real and imaginary part of C[-k].
+    const double sa = j ? -1.0 : 1.0, sb = j ? 1.0 : -1.0;
+    const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
+    wfft::mirror_store(re, wave_tiles, q, h);
+    wfft::pipelined_for32<4, double>(
+        [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
+        [&](auto ic, const double& cx) WFFT_INLINE {
+          constexpr int s = decltype(ic)::value;
+          re[s] = re[s] * sa + cx;           // j = 0: Re D_0;  j = 1: Im D_1
+        });
+    wfft::mirror_store(im, wave_tiles, q, h);
+    wfft::pipelined_for32<4, double>(
+        [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
+        [&](auto ic, const double& my) WFFT_INLINE {
+          constexpr int s = decltype(ic)::value;
+          im[s] = my * sb + im[s];           // j = 0: Im D_0;  j = 1: Re D_1
+        });
+    if (j == 0) {
+      kp.run(load_k, [&](auto ic, const cplx& k) WFFT_INLINE {
+        constexpr int s = decltype(ic)::value;
+        const double dr = re[s], di = im[s];
+        re[s] = dr * k.x - di * k.y;
+        im[s] = dr * k.y + di * k.x;
+      });
+    } else {
+      kp.run(load_k, [&](auto ic, const cplx& k) WFFT_INLINE {
+        constexpr int s = decltype(ic)::value;
+        const double dr = im[s], di = re[s];
+        re[s] = dr * k.x - di * k.y;
+        im[s] = dr * k.y + di * k.x;
+      });
+    }
+    wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate, []() WFFT_INLINE {});
+    }
+  }
+  __syncthreads();
+
+  if (HOOK) {
+    for (int x = threadIdx.x; x < 2 * kN; x += 64 * W) args.acc_io[(size_t)b * 3 * kN + x] = accL[x];
+  } else {
+    // extract_lwe, src/tlwe.rs:159-180 (k = 1): a[0] = acc0[0], a[t] = -acc0[N-t].
+    int32_t* oa = args.out_a + (size_t)b * kN;
+    for (int t = threadIdx.x; t < kN; t += 64 * W) oa[t] = t == 0 ? accL[0] : wneg(accL[kN - t]);
+    if (threadIdx.x == 0) {
+      const int32_t barb = args.barb[b];                       // bootstrapping.rs:58-96
+      args.out_b[b] = barb >= 0 ? args.mu : wneg(args.mu);
+    }
   }
 }
 
@@ -597,6 +771,7 @@ __global__ void ks_pack_kernel(const int32_t* __restrict__ ks_a, const int32_t* 
 struct tfhe_hip_ctx {
   int device = 0;
   int num_cus = 256;
+  int br_mode = TFHE_HIP_BR_AUTO;
   hipStream_t stream = nullptr;
   std::string err;
   bool have_keys = false;
@@ -746,17 +921,33 @@ int launch_blind_rotate(tfhe_hip_ctx* ctx, const int32_t* bara, const int32_t* b
   BlindRotateArgs a;
   a.bara = bara; a.barb = barb; a.bkfft = ctx->bkfft; a.tables = ctx->tables;
   a.acc_io = acc_io; a.out_a = out_a; a.out_b = out_b; a.mu = mu; a.n = ctx->P.n; a.B = (int32_t)B;
-  // one persistent workgroup per compute unit (160 KiB of LDS each)
-  const unsigned grid = (unsigned)std::min<size_t>((B + kWavesPerBlock - 1) / kWavesPerBlock,
-                                                   (size_t)ctx->num_cus);
   const bool hook = acc_io != nullptr;
+  // Batches that cannot give every SIMD its own ciphertext run with one
+  // workgroup per ciphertext (2 l wavefronts each, a third of the latency);
+  // larger ones with one persistent workgroup per compute unit (160 KiB of LDS
+  // each), one ciphertext per wavefront.
+  const bool split = ctx->br_mode == TFHE_HIP_BR_SPLIT ||
+                     (ctx->br_mode == TFHE_HIP_BR_AUTO && B <= 2 * (size_t)ctx->num_cus);
   ProfileScope prof(ctx, 1);
-  if (ctx->P.l == 2) {
-    if (hook) hipLaunchKernelGGL((blind_rotate_kernel<2, 10, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((blind_rotate_kernel<2, 10, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+  if (split) {
+    const dim3 grid((unsigned)B);
+    if (ctx->P.l == 2) {
+      if (hook) hipLaunchKernelGGL((blind_rotate_split_kernel<2, 10, true, 1>), grid, dim3(256), 0, ctx->stream, a);
+      else hipLaunchKernelGGL((blind_rotate_split_kernel<2, 10, false, 1>), grid, dim3(256), 0, ctx->stream, a);
+    } else {
+      if (hook) hipLaunchKernelGGL((blind_rotate_split_kernel<3, 7, true, 2>), grid, dim3(192), 0, ctx->stream, a);
+      else hipLaunchKernelGGL((blind_rotate_split_kernel<3, 7, false, 2>), grid, dim3(192), 0, ctx->stream, a);
+    }
   } else {
-    if (hook) hipLaunchKernelGGL((blind_rotate_kernel<3, 7, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((blind_rotate_kernel<3, 7, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    const unsigned grid = (unsigned)std::min<size_t>((B + kWavesPerBlock - 1) / kWavesPerBlock,
+                                                     (size_t)ctx->num_cus);
+    if (ctx->P.l == 2) {
+      if (hook) hipLaunchKernelGGL((blind_rotate_kernel<2, 10, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+      else hipLaunchKernelGGL((blind_rotate_kernel<2, 10, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    } else {
+      if (hook) hipLaunchKernelGGL((blind_rotate_kernel<3, 7, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+      else hipLaunchKernelGGL((blind_rotate_kernel<3, 7, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
+    }
   }
   HIP_TRY(ctx, hipGetLastError());
   return 0;
@@ -833,6 +1024,14 @@ int tfhe_hip_create(tfhe_hip_ctx** out, int device) {
     return TFHE_HIP_ERR_RUNTIME;
   }
   *out = ctx;
+  return 0;
+}
+
+int tfhe_hip_set_blind_rotate_mode(tfhe_hip_ctx* ctx, int mode) {
+  if (!ctx) return TFHE_HIP_ERR_ARG;
+  if (mode != TFHE_HIP_BR_AUTO && mode != TFHE_HIP_BR_BATCH && mode != TFHE_HIP_BR_SPLIT)
+    return fail(ctx, TFHE_HIP_ERR_ARG, "unknown blind-rotate mode");
+  ctx->br_mode = mode;
   return 0;
 }
 

@@ -90,6 +90,12 @@ class Engine:
         self._check(self.lib.tfhe_hip_set_stream(
             self.ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
+    BR_MODES = {"auto": 0, "batch": 1, "split": 2}
+
+    def set_blind_rotate_mode(self, mode):
+        """'batch' = one ciphertext per wavefront, 'split' = one per workgroup, 'auto' by batch size."""
+        self._check(self.lib.tfhe_hip_set_blind_rotate_mode(self.ctx, self.BR_MODES[mode]))
+
     def profile_enable(self, on=True):
         self._check(self.lib.tfhe_hip_profile_enable(self.ctx, int(on)))
 
