@@ -137,6 +137,26 @@ int tfhe_hip_gate_dev(tfhe_hip_ctx* ctx, int gate, const int32_t* ca_a, const in
                       const int32_t* cc_b, int32_t* out_a, int32_t* out_b, double* var_out,
                       size_t B);
 
+/* circuits::add (src/circuits/circuits.rs:105-120, full_adder :83-97), the
+ * ripple-carry adder, on `count` independent pairs of `bits`-bit operands, run
+ * level by level so that every launch holds the gates of all instances that are
+ * ready: xor(a, b) and and(a, b) of all bits first, then per bit
+ * {xor(x, carry), and(carry, x)} as one batch and or(t, g) as the next.
+ * Intermediate ciphertexts never leave the GPU.
+ * Operands and sums are bit-sliced: a_a, b_a, sum_a [bits][count][n]; a_b, b_b,
+ * sum_b [bits][count] (bit 0 = least significant, the first element of the
+ * reference's slices); carry_a [count][n], carry_b [count].  sum_var
+ * [bits][count] and carry_var [count] may be NULL.  bits = 0 returns
+ * carry = constant(false), as the reference's fold does. */
+int tfhe_hip_circuit_add(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_t* a_b,
+                         const int32_t* b_a, const int32_t* b_b, int32_t* sum_a, int32_t* sum_b,
+                         int32_t* carry_a, int32_t* carry_b, double* sum_var, double* carry_var,
+                         size_t count, int bits);
+int tfhe_hip_circuit_add_dev(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_t* a_b,
+                             const int32_t* b_a, const int32_t* b_b, int32_t* sum_a, int32_t* sum_b,
+                             int32_t* carry_a, int32_t* carry_b, double* sum_var, double* carry_var,
+                             size_t count, int bits);
+
 /* poly_multiplier / torus_polynomial_mul_r (src/numerics.rs:138-155,185-261)
  * on B independent pairs of N-coefficient polynomials d [B][N], s [B][N].
  * accumulate == 0: out [B][2N-1] = the full saturated product;

@@ -88,6 +88,33 @@ int main() {
       CHECK(out[i].coefficients == one.coefficients && out[i].b == one.b, "batch nand %d", i);
     }
   }
+  // circuits: the device executor of add against full_adder composed gate by gate
+  {
+    const int bits = 2;
+    std::vector<LweSample> a, b;
+    for (int i = 0; i < bits; i++) { a.push_back(encrypt(i & 1, sk)); b.push_back(encrypt(true, sk)); }
+    const auto [sum, carry] = circuits::add(a, b, ck);
+    LweSample c = constant(false, ck);
+    for (int i = 0; i < bits; i++) {
+      const auto [s1, c1] = circuits::full_adder(a[i], b[i], c, ck);
+      CHECK(sum[i].coefficients == s1.coefficients && sum[i].b == s1.b &&
+                sum[i].current_variance == s1.current_variance, "add: sum bit %d", i);
+      c = c1;
+    }
+    CHECK(carry.coefficients == c.coefficients && carry.b == c.b && carry.current_variance == c.current_variance,
+          "add: carry");
+    const LweSample e = circuits::eq(a, b, ck);
+    LweSample res = constant(true, ck);
+    for (int i = 0; i < bits; i++) res = and_(res, circuits::eq_bit(a[i], b[i], ck), ck);
+    CHECK(e.coefficients == res.coefficients && e.b == res.b, "eq");
+    const LweSample le = circuits::compare(a, b, ck);
+    LweSample rim = constant(true, ck);
+    for (int i = 0; i < bits; i++) rim = mux(xor_(a[i], b[i], ck), b[i], rim, ck);
+    CHECK(le.coefficients == rim.coefficients && le.b == rim.b, "compare");
+    bool threw = false;
+    try { (void)circuits::add(a, std::vector<LweSample>{b[0]}, ck); } catch (const std::runtime_error&) { threw = true; }
+    CHECK(threw, "add: length mismatch not reported");
+  }
   // error behaviour: malformed input is reported (the crate panics)
   {
     bool threw = false;

@@ -178,6 +178,41 @@ def test_gates_small_n(eng, tag):
             assert var[i] == wv, (g, i)
 
 
+# ---- circuits::add, level-batched ---------------------------------------------------
+
+def _oracle_add(P, K, a, b, mode):
+    """full_adder / add of /root/reference/src/circuits/circuits.rs:83-120 as a
+    composition of oracle gates; a, b: lists of (a, b, var) samples, bit 0 first."""
+    carry = (np.zeros(P.n, np.int32), np.int32(-(1 << 29)), 0.0)      # constant(false)
+    sums = []
+    for x, y in zip(a, b):
+        a_b_xor = orc.gate(P, "xor", K, x, y, None, mode)
+        s_ = orc.gate(P, "xor", K, a_b_xor, carry, None, mode)
+        t = orc.gate(P, "and", K, carry, a_b_xor, None, mode)
+        g = orc.gate(P, "and", K, x, y, None, mode)
+        carry = orc.gate(P, "or", K, t, g, None, mode)
+        sums.append(s_)
+    return sums, carry
+
+
+@pytest.mark.parametrize("tag,bits,count", [("l2", 4, 5), ("l3", 3, 2), ("l2", 0, 3), ("l2", 1, 1)])
+def test_circuit_add(eng, tag, bits, count):
+    l, bg = SHAPES[tag]
+    P = orc.small_params(n=6, l=l, bg_bit=bg)
+    K = orc.generate_synthetic_keys(P, 80)
+    _load(eng, P, K)
+    A = (orc.uniform_i32(81, (bits, count, P.n)), orc.uniform_i32(82, (bits, count)))
+    Bv = (orc.uniform_i32(83, (bits, count, P.n)), orc.uniform_i32(84, (bits, count)))
+    (sa, sb), (ca, cb), sv, cv = eng.circuit_add(A, Bv, want_var=True)
+    for c in range(count):
+        a = [(A[0][i, c], A[1][i, c], 0.0) for i in range(bits)]
+        b = [(Bv[0][i, c], Bv[1][i, c], 0.0) for i in range(bits)]
+        sums, carry = _oracle_add(P, K, a, b, orc.MUL_EXACT)
+        for i in range(bits):
+            assert (sa[i, c] == sums[i][0]).all() and sb[i, c] == sums[i][1] and sv[i, c] == sums[i][2], (c, i)
+        assert (ca[c] == carry[0]).all() and cb[c] == carry[1] and cv[c] == carry[2], c
+
+
 # ---- full-size parameter sets -------------------------------------------------------
 
 @pytest.fixture(scope="module")

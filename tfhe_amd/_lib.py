@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("TFHE_HIP_LIB") or os.path.join(HERE, "libtfhe_hip.so"
 
 SYMBOLS = [
     "tfhe_hip_create", "tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_set_stream", "tfhe_hip_set_blind_rotate_mode",
+    "tfhe_hip_circuit_add", "tfhe_hip_circuit_add_dev",
     "tfhe_hip_synchronize", "tfhe_hip_load_keys", "tfhe_hip_key_blob_sizes",
     "tfhe_hip_export_keys_dev", "tfhe_hip_import_keys_dev", "tfhe_hip_bootstrap",
     "tfhe_hip_bootstrap_dev", "tfhe_hip_bootstrap_noks", "tfhe_hip_bootstrap_noks_dev",
@@ -63,6 +64,8 @@ def load():
                                        f64p, sz]
     for name in ("tfhe_hip_polymul", "tfhe_hip_polymul_dev"):
         getattr(lib, name).argtypes = [vp, i32p, i32p, i32p, C.c_int, sz]
+    for name in ("tfhe_hip_circuit_add", "tfhe_hip_circuit_add_dev"):
+        getattr(lib, name).argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i32p, i32p, i32p, f64p, f64p, sz, C.c_int]
     lib.tfhe_hip_profile_enable.argtypes = [vp, C.c_int]
     lib.tfhe_hip_profile_read.argtypes = [vp, C.POINTER(C.c_double * 3), C.POINTER(C.c_int * 3)]
     lib.tfhe_hip_extprod.argtypes = [vp, i32p, C.c_int, i32p, sz]

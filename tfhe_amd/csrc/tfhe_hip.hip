@@ -753,6 +753,11 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(
 }
 
 // Packs the key-switch key into rows [a_0 .. a_{n-1}, b, 0 pad] of row_stride int32.
+__global__ void fill_kernel(int32_t* __restrict__ p, int32_t v, size_t count) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) p[i] = v;
+}
+
 __global__ void ks_pack_kernel(const int32_t* __restrict__ ks_a, const int32_t* __restrict__ ks_b,
                                int n, int row_stride, size_t rows, int32_t* __restrict__ dst) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -784,6 +789,9 @@ struct tfhe_hip_ctx {
   // scratch, grown on demand
   void* scratch = nullptr;
   size_t scratch_bytes = 0;
+  // workspace of the circuit executor, grown on demand
+  void* work = nullptr;
+  size_t work_bytes = 0;
   // optional per-kernel timing (tfhe_hip_profile_*)
   bool profile = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];   // prologue, blind rotate, key switch
@@ -989,6 +997,63 @@ int need_keys(tfhe_hip_ctx* ctx) {
   return 0;
 }
 
+// Several two-input gates with the same test-vector value mu, run as ONE
+// blind rotation over the concatenated batch (prologue and key switch per
+// gate, since their operands and results live in different arrays).
+struct GateItem {
+  int gate;
+  const int32_t *ca_a, *ca_b, *cb_a, *cb_b;
+  int32_t *out_a, *out_b;
+  double* var_out;
+  size_t B;
+};
+
+int run_gate_group(tfhe_hip_ctx* ctx, const GateItem* items, int count) {
+  size_t total = 0;
+  Weights w0{};
+  for (int k = 0; k < count; k++) {
+    Weights w;
+    if (!gate_weights(items[k].gate, &w)) return fail(ctx, TFHE_HIP_ERR_ARG, "unknown gate id");
+    if (k == 0) w0 = w;
+    else if (w.mu != w0.mu) return fail(ctx, TFHE_HIP_ERR_ARG, "gates of a group must share mu");
+    total += items[k].B;
+  }
+  if (total == 0) return 0;
+  Scratch s;
+  if (int rc = get_scratch(ctx, total, false, &s)) return rc;
+  const size_t n = ctx->P.n;
+  size_t off = 0;
+  for (int k = 0; k < count; k++) {
+    const GateItem& g = items[k];
+    Weights w;
+    gate_weights(g.gate, &w);
+    if (g.B == 0) continue;
+    if (int rc = launch_prologue(ctx, g.ca_a, g.ca_b, g.cb_a, g.cb_b, w.wa, w.wb, w.c, g.B, s.bara + off * n,
+                                 s.barb + off)) return rc;
+    off += g.B;
+  }
+  if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w0.mu, nullptr, s.ea, s.eb, total)) return rc;
+  off = 0;
+  for (int k = 0; k < count; k++) {
+    const GateItem& g = items[k];
+    if (g.B == 0) continue;
+    if (int rc = launch_keyswitch(ctx, s.ea + off * kN, s.eb + off, nullptr, nullptr, 0, g.out_a, g.out_b,
+                                  g.var_out, g.B)) return rc;
+    off += g.B;
+  }
+  return 0;
+}
+
+int ensure_work(tfhe_hip_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->work_bytes) return 0;
+  if (ctx->work) HIP_TRY(ctx, hipFree(ctx->work));
+  ctx->work = nullptr;
+  ctx->work_bytes = 0;
+  HIP_TRY(ctx, hipMalloc(&ctx->work, bytes));
+  ctx->work_bytes = bytes;
+  return 0;
+}
+
 // Staging helpers for the host-pointer entry points.
 struct DevBuf {
   void* p = nullptr;
@@ -1042,6 +1107,7 @@ void tfhe_hip_destroy(tfhe_hip_ctx* ctx) {
   if (ctx->bkfft) (void)hipFree(ctx->bkfft);
   if (ctx->ksblob) (void)hipFree(ctx->ksblob);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->work) (void)hipFree(ctx->work);
   delete ctx;
 }
 
@@ -1313,6 +1379,89 @@ int tfhe_hip_gate(tfhe_hip_ctx* ctx, int gate, const int32_t* ca_a, const int32_
                                  (int32_t*)ob.p, var_out ? (double*)ov.p : nullptr, B)) return rc;
   COPY_BACK(out_a, oa, B * n * 4) COPY_BACK(out_b, ob, B * 4)
   if (var_out) COPY_BACK(var_out, ov, B * 8)
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+// circuits::add (src/circuits/circuits.rs:105-120) on `count` independent
+// operand pairs, level by level: x = xor(a, b) and g = and(a, b) of every bit
+// of every instance first (they do not depend on the carry), then per bit
+// sum = xor(x, carry) and t = and(carry, x) in one blind rotation, and
+// carry' = or(t, g) (full_adder, circuits.rs:83-97).
+int tfhe_hip_circuit_add_dev(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_t* a_b,
+                             const int32_t* b_a, const int32_t* b_b, int32_t* sum_a, int32_t* sum_b,
+                             int32_t* carry_a, int32_t* carry_b, double* sum_var, double* carry_var,
+                             size_t count, int bits) {
+  if (int rc = need_keys(ctx)) return rc;
+  if (bits < 0) return fail(ctx, TFHE_HIP_ERR_ARG, "bits must be >= 0");
+  if (count == 0) return 0;
+  if (!carry_a || !carry_b || (bits > 0 && (!a_a || !a_b || !b_a || !b_b || !sum_a || !sum_b)))
+    return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
+  const size_t n = ctx->P.n, sa = count * n, sb = count;      // one bit slice: masks, bodies
+  // workspace: x, g [bits] slices; t, carry ping-pong: 3 slices
+  const size_t slice = sa + sb;
+  if (int rc = ensure_work(ctx, (2 * (size_t)bits + 3) * slice * sizeof(int32_t))) return rc;
+  int32_t* w = (int32_t*)ctx->work;
+  int32_t *x_a = w, *x_b = x_a + (size_t)bits * sa;
+  int32_t *g_a = x_b + (size_t)bits * sb, *g_b = g_a + (size_t)bits * sa;
+  int32_t *t_a = g_b + (size_t)bits * sb, *t_b = t_a + sa;
+  int32_t *c0_a = t_b + sb, *c0_b = c0_a + sa, *c1_a = c0_b + sb, *c1_b = c1_a + sa;
+  // carry-independent gates of all bits, in groups of at most kMaxGroup ciphertexts
+  constexpr size_t kMaxGroup = 65536;
+  const int bits_per_group = (int)std::max<size_t>(1, kMaxGroup / (2 * count));
+  for (int i0 = 0; i0 < bits; i0 += bits_per_group) {
+    const size_t nb = (size_t)std::min(bits_per_group, bits - i0);
+    const GateItem items[2] = {
+        {TFHE_HIP_XOR, a_a + i0 * sa, a_b + i0 * sb, b_a + i0 * sa, b_b + i0 * sb, x_a + i0 * sa, x_b + i0 * sb, nullptr, nb * count},
+        {TFHE_HIP_AND, a_a + i0 * sa, a_b + i0 * sb, b_a + i0 * sa, b_b + i0 * sb, g_a + i0 * sa, g_b + i0 * sb, nullptr, nb * count}};
+    if (int rc = run_gate_group(ctx, items, 2)) return rc;
+  }
+  // carry_in = constant(false) = trivial(encode_message(-1, 8)), src/gates.rs:12-19
+  int32_t *cin_a = c0_a, *cin_b = c0_b, *cout_a = c1_a, *cout_b = c1_b;
+  if (bits == 0) { cin_a = carry_a; cin_b = carry_b; }
+  HIP_TRY(ctx, hipMemsetAsync(cin_a, 0, sa * sizeof(int32_t), ctx->stream));
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((sb + 255) / 256)), dim3(256), 0, ctx->stream, cin_b,
+                     -(1 << 29), sb);
+  HIP_TRY(ctx, hipGetLastError());
+  for (int i = 0; i < bits; i++) {
+    const bool last = i == bits - 1;
+    const GateItem lvl1[2] = {
+        {TFHE_HIP_XOR, x_a + i * sa, x_b + i * sb, cin_a, cin_b, sum_a + i * sa, sum_b + i * sb,
+         sum_var ? sum_var + i * sb : nullptr, count},
+        {TFHE_HIP_AND, cin_a, cin_b, x_a + i * sa, x_b + i * sb, t_a, t_b, nullptr, count}};
+    if (int rc = run_gate_group(ctx, lvl1, 2)) return rc;
+    const GateItem lvl2 = {TFHE_HIP_OR, t_a, t_b, g_a + i * sa, g_b + i * sb, last ? carry_a : cout_a,
+                           last ? carry_b : cout_b, last ? carry_var : nullptr, count};
+    if (int rc = run_gate_group(ctx, &lvl2, 1)) return rc;
+    std::swap(cin_a, cout_a);
+    std::swap(cin_b, cout_b);
+  }
+  if (bits == 0 && carry_var) HIP_TRY(ctx, hipMemsetAsync(carry_var, 0, sb * sizeof(double), ctx->stream));
+  return 0;
+}
+
+int tfhe_hip_circuit_add(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_t* a_b, const int32_t* b_a,
+                         const int32_t* b_b, int32_t* sum_a, int32_t* sum_b, int32_t* carry_a,
+                         int32_t* carry_b, double* sum_var, double* carry_var, size_t count, int bits) {
+  if (int rc = need_keys(ctx)) return rc;
+  if (bits < 0) return fail(ctx, TFHE_HIP_ERR_ARG, "bits must be >= 0");
+  if (count == 0) return 0;
+  if (!carry_a || !carry_b || (bits > 0 && (!a_a || !a_b || !b_a || !b_b || !sum_a || !sum_b)))
+    return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
+  const size_t n = ctx->P.n, ma = (size_t)bits * count * n * 4, mb = (size_t)bits * count * 4;
+  STAGE_IN(daa, bits ? a_a : nullptr, ma) STAGE_IN(dab, bits ? a_b : nullptr, mb)
+  STAGE_IN(dba, bits ? b_a : nullptr, ma) STAGE_IN(dbb, bits ? b_b : nullptr, mb)
+  STAGE_OUT(dsa, std::max<size_t>(ma, 4)) STAGE_OUT(dsb, std::max<size_t>(mb, 4))
+  STAGE_OUT(dsv, std::max<size_t>(2 * mb, 8))
+  STAGE_OUT(dca, count * n * 4) STAGE_OUT(dcb, count * 4) STAGE_OUT(dcv, count * 8)
+  if (int rc = tfhe_hip_circuit_add_dev(ctx, (int32_t*)daa.p, (int32_t*)dab.p, (int32_t*)dba.p,
+                                        (int32_t*)dbb.p, (int32_t*)dsa.p, (int32_t*)dsb.p, (int32_t*)dca.p,
+                                        (int32_t*)dcb.p, sum_var ? (double*)dsv.p : nullptr,
+                                        carry_var ? (double*)dcv.p : nullptr, count, bits)) return rc;
+  if (bits) { COPY_BACK(sum_a, dsa, ma) COPY_BACK(sum_b, dsb, mb) }
+  if (bits && sum_var) COPY_BACK(sum_var, dsv, 2 * mb)
+  COPY_BACK(carry_a, dca, count * n * 4) COPY_BACK(carry_b, dcb, count * 4)
+  if (carry_var) COPY_BACK(carry_var, dcv, count * 8)
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }

@@ -152,6 +152,24 @@ class Engine:
                                            _p(var), B))
         return (out_a, out_b, var) if want_var else (out_a, out_b)
 
+    def circuit_add(self, a, b, want_var=False):
+        """circuits::add on many instances.  a, b: (masks [bits][count][n], bodies [bits][count]),
+        bit 0 first.  Returns (sum, carry[, sum_var, carry_var]) with sum = (masks, bodies) in the
+        same layout and carry = ([count][n], [count])."""
+        a_a, a_b, b_a, b_b = _np(a[0]), _np(a[1]), _np(b[0]), _np(b[1])
+        bits, count = a_b.shape
+        n = self.params.n
+        sum_a, sum_b = np.empty((bits, count, n), np.int32), np.empty((bits, count), np.int32)
+        car_a, car_b = np.empty((count, n), np.int32), np.empty(count, np.int32)
+        sv = np.empty((bits, count), np.float64) if want_var else None
+        cv = np.empty(count, np.float64) if want_var else None
+        self._check(self.lib.tfhe_hip_circuit_add(self.ctx, _p(a_a), _p(a_b), _p(b_a), _p(b_b),
+                                                  _p(sum_a), _p(sum_b), _p(car_a), _p(car_b), _p(sv),
+                                                  _p(cv), count, bits))
+        if want_var:
+            return (sum_a, sum_b), (car_a, car_b), sv, cv
+        return (sum_a, sum_b), (car_a, car_b)
+
     def polymul(self, d, s, accumulate_into=None):
         d, s = _np(d), _np(s)
         B = d.shape[0]
@@ -181,6 +199,13 @@ class Engine:
         self._check(self.lib.tfhe_hip_gate_dev(self.ctx, GATE_ID[gate], _tp(ca_a), _tp(ca_b),
                                                _tp(cb_a), _tp(cb_b), _tp(cc_a), _tp(cc_b),
                                                _tp(out_a), _tp(out_b), _tp(var), ca_b.numel()))
+
+    def circuit_add_dev(self, a_a, a_b, b_a, b_b, sum_a, sum_b, carry_a, carry_b, sum_var=None,
+                        carry_var=None):
+        bits, count = a_b.shape
+        self._check(self.lib.tfhe_hip_circuit_add_dev(
+            self.ctx, _tp(a_a), _tp(a_b), _tp(b_a), _tp(b_b), _tp(sum_a), _tp(sum_b), _tp(carry_a),
+            _tp(carry_b), _tp(sum_var), _tp(carry_var), count, bits))
 
     def bootstrap_dev(self, mu, a, b, out_a, out_b, var=None):
         self._check(self.lib.tfhe_hip_bootstrap_dev(self.ctx, mu, _tp(a), _tp(b), _tp(out_a),

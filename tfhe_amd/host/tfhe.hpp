@@ -356,4 +356,114 @@ inline LweSample tfhe_bootstrap(const CloudKey& bk, Torus32 mu, const LweSample&
   return out;
 }
 
+// src/circuits/circuits.rs.  Same names, argument order and panics (as
+// std::runtime_error) as the crate; every gate runs on the GPU.  `add` also
+// comes in a many-instances form that runs level by level on the device.
+namespace circuits {
+
+namespace detail {
+// Less than or equal to comparator with carry input (circuits.rs:44-47).
+inline LweSample le(const LweSample& a, const LweSample& b, const LweSample& rim, const CloudKey& key) {
+  const LweSample condition = xor_(a, b, key);
+  return mux(condition, b, rim, key);
+}
+}  // namespace detail
+
+// `a <= b` on little-endian bit vectors (circuits.rs:33-41).
+inline LweSample compare(const std::vector<LweSample>& a, const std::vector<LweSample>& b,
+                         const CloudKey& key) {
+  LweSample carry = constant(true, key);
+  if (a.size() != b.size()) throw std::runtime_error("compare: operands differ in length");
+  for (size_t i = 0; i < a.size(); i++) carry = detail::le(a[i], b[i], carry, key);
+  return carry;
+}
+
+// circuits.rs:65-69
+inline LweSample eq_bit(const LweSample& a, const LweSample& b, const CloudKey& key) {
+  const LweSample res = xor_(a, b, key);
+  return xor_(res, constant(true, key), key);
+}
+
+// circuits.rs:50-62; the per-bit equalities are independent and run as two batches.
+inline LweSample eq(const std::vector<LweSample>& a, const std::vector<LweSample>& b, const CloudKey& key) {
+  if (a.empty()) throw std::runtime_error("eq: empty operand");
+  if (a.size() != b.size()) throw std::runtime_error("eq: operands differ in length");
+  const std::vector<LweSample> ones(a.size(), constant(true, key));
+  const std::vector<LweSample> bits = xor_(xor_(a, b, key), ones, key);
+  LweSample res = constant(true, key);
+  for (const LweSample& bit : bits) res = and_(res, bit, key);
+  return res;
+}
+
+// circuits.rs:77-79
+inline std::pair<LweSample, LweSample> half_adder(const LweSample& a, const LweSample& b,
+                                                  const CloudKey& key) {
+  return {xor_(a, b, key), and_(a, b, key)};
+}
+
+// circuits.rs:83-97
+inline std::pair<LweSample, LweSample> full_adder(const LweSample& a, const LweSample& b,
+                                                  const LweSample& carry_in, const CloudKey& key) {
+  const LweSample a_b_xor = xor_(a, b, key);
+  const LweSample sum = xor_(a_b_xor, carry_in, key);
+  const LweSample carry_in_and_a_xor_b = and_(carry_in, a_b_xor, key);
+  const LweSample a_and_b = and_(a, b, key);
+  return {sum, or_(carry_in_and_a_xor_b, a_and_b, key)};
+}
+
+// Ripple-carry adders of many independent operand pairs at once
+// (circuits.rs:105-120 per pair): a[i], b[i] are the little-endian bit vectors
+// of pair i, all of the same length.  Returns (sum bits, carry) per pair.
+inline std::vector<std::pair<std::vector<LweSample>, LweSample>> add(
+    const std::vector<std::vector<LweSample>>& a, const std::vector<std::vector<LweSample>>& b,
+    const CloudKey& key) {
+  if (!key.device) throw std::runtime_error("CloudKey has no device context");
+  if (a.size() != b.size()) throw std::runtime_error("add: numbers of operands differ");
+  const size_t count = a.size(), n = key.params.in_out_params.n;
+  if (count == 0) return {};
+  const size_t bits = a[0].size();
+  std::vector<int32_t> aa(bits * count * n), ab(bits * count), ba(aa.size()), bb(ab.size());
+  for (size_t c = 0; c < count; c++) {
+    if (a[c].size() != bits || b[c].size() != bits)
+      throw std::runtime_error("Cannot add two numbers with different number of bits!");
+    for (size_t i = 0; i < bits; i++) {
+      if (a[c][i].coefficients.size() != n || b[c][i].coefficients.size() != n)
+        throw std::runtime_error("add: sample size differs from n");
+      std::copy(a[c][i].coefficients.begin(), a[c][i].coefficients.end(), aa.begin() + (i * count + c) * n);
+      std::copy(b[c][i].coefficients.begin(), b[c][i].coefficients.end(), ba.begin() + (i * count + c) * n);
+      ab[i * count + c] = a[c][i].b;
+      bb[i * count + c] = b[c][i].b;
+    }
+  }
+  std::vector<int32_t> sa(aa.size()), sb(ab.size()), ca(count * n), cb(count);
+  std::vector<double> sv(ab.size()), cv(count);
+  key.device->check(tfhe_hip_circuit_add(key.device->ctx, aa.data(), ab.data(), ba.data(), bb.data(),
+                                         sa.data(), sb.data(), ca.data(), cb.data(), sv.data(), cv.data(),
+                                         count, (int)bits));
+  std::vector<std::pair<std::vector<LweSample>, LweSample>> out(count);
+  for (size_t c = 0; c < count; c++) {
+    out[c].first.resize(bits);
+    for (size_t i = 0; i < bits; i++) {
+      LweSample& s = out[c].first[i];
+      s.coefficients.assign(sa.begin() + (i * count + c) * n, sa.begin() + (i * count + c + 1) * n);
+      s.b = sb[i * count + c];
+      s.current_variance = sv[i * count + c];
+    }
+    out[c].second.coefficients.assign(ca.begin() + c * n, ca.begin() + (c + 1) * n);
+    out[c].second.b = cb[c];
+    out[c].second.current_variance = bits ? cv[c] : 0.0;
+  }
+  return out;
+}
+
+// circuits.rs:105-120
+inline std::pair<std::vector<LweSample>, LweSample> add(const std::vector<LweSample>& a,
+                                                        const std::vector<LweSample>& b,
+                                                        const CloudKey& key) {
+  if (a.size() != b.size()) throw std::runtime_error("Cannot add two numbers with different number of bits!");
+  return add(std::vector<std::vector<LweSample>>{a}, std::vector<std::vector<LweSample>>{b}, key)[0];
+}
+
+}  // namespace circuits
+
 }  // namespace tfhe
