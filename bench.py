@@ -9,6 +9,12 @@ resident in HBM before the timed region.  Keys are synthetic (every entry
 uniform), so no stage degenerates to zeros; the kernels are data independent.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--level 80|128]
+                  [--workload nand|add32|polymul]
+
+--workload nand (default) is the headline metric.  add32 times the level-batched
+ripple-carry adder (circuits::add on 32-bit operands, 160 gates per instance,
+--batch instances per GPU per step); polymul times isolated polynomial products
+(--batch products per step).  Each prints its own single JSON line.
 
 For N > 1 launch with torch.distributed.run (one rank per GPU); rank 0 builds
 the keys, their FFT-domain form is broadcast once over RCCL, and every rank
@@ -88,6 +94,105 @@ def cpu_baseline(level):
                       f"src/numerics.rs:235-251, not the Rust binary"}
 
 
+def side_workload(args):
+    """Secondary workloads (not the headline metric): one JSON line each."""
+    import torch
+    import torch.distributed as dist
+
+    import tfhe_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+    lv = LEVELS[args.level]
+    eng = tfhe_amd.Engine(dev.index)
+    eng.use_torch_stream()
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321 + rank)
+
+    def rnd(shape, lo=-2**31, hi=2**31):
+        return torch.randint(lo, hi, shape, dtype=torch.int64, device=dev, generator=g).to(torch.int32)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if args.workload == "add32":
+        params = tfhe_amd.make_params(lv["n"], l=lv["l"], bg_bit=lv["bg_bit"])
+        if rank == 0:
+            K = synthetic_keys(args.level, 0xC0FFEE + 5)
+            eng.load_keys(params, K["bk"], K["ks_a"], K["ks_b"], K["ks_var"])
+        if world > 1:
+            from tfhe_amd import parallel
+            parallel.replicate_keys(eng, params, dev, src=0)
+        count = args.batch if args.batch != 16384 else 4096
+        bits, n = 32, lv["n"]
+        a_a, a_b, b_a, b_b = rnd((bits, count, n)), rnd((bits, count)), rnd((bits, count, n)), rnd((bits, count))
+        s_a = torch.empty((bits, count, n), dtype=torch.int32, device=dev)
+        s_b = torch.empty((bits, count), dtype=torch.int32, device=dev)
+        c_a = torch.empty((count, n), dtype=torch.int32, device=dev)
+        c_b = torch.empty((count,), dtype=torch.int32, device=dev)
+
+        def step():
+            eng.circuit_add_dev(a_a, a_b, b_a, b_b, s_a, s_b, c_a, c_b)
+        units, unit_name = 5 * bits * count, "gates/s"
+        workload = (f"circuits::add, {count} instances of {bits}-bit operands per GPU per step "
+                    f"(160 bootstrapped gates each, 65 dependency levels), Bit{args.level}")
+        metric = "bootstrapped gates/sec inside level-batched 32-bit ripple-carry adders"
+    else:
+        B = args.batch if args.batch != 16384 else 65536
+        half = 512 if args.level == 80 else 64
+        d, s_ = rnd((B, 1024), -half, half), rnd((B, 1024))
+        out = torch.empty((B, 2047), dtype=torch.int32, device=dev)
+
+        def step():
+            eng.polymul_dev(d, s_, out)
+        units, unit_name = B, "products/s"
+        workload = (f"{B} independent products of a digit polynomial (|d| < {half}) with a uniform "
+                    f"Torus32 polynomial, N = 1024, full 2047-coefficient result")
+        metric = "isolated polynomial products/sec (poly_multiplier)"
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        value = units * world * args.steps / elapsed
+        res = {"metric": metric, "value": value, "unit": unit_name, "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": workload}}
+        if args.workload == "polymul":
+            flop = 2 * FLOP_FFT + FLOP_FFT + FLOP_POINTWISE
+            bytes_ = 1024 * 4 * 2 + 2047 * 4
+            res["roofline"] = {"bound": "fp64_valu", "achieved": value * flop / 1e12,
+                               "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": value * flop / 1e12 / FP64_VECTOR_PEAK_TFLOPS, "traffic": None,
+                               "hbm_GBps_algorithmic": value * bytes_ / 1e9}
+        if args.workload == "add32":
+            res["additions_per_sec"] = value / (5 * 32)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,7 +202,10 @@ def main():
     ap.add_argument("--level", type=int, default=80, choices=[80, 128])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--workload", default="nand", choices=["nand", "add32", "polymul"])
     args = ap.parse_args()
+    if args.workload != "nand":
+        return side_workload(args)
 
     import torch
     import torch.distributed as dist
@@ -170,13 +278,13 @@ def main():
     p50 = None
     if rank == 0 and not args.no_latency:
         lat = []
-        for _ in range(21):
+        for _ in range(201):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             eng.gate_dev("nand", ca_a[:1], ca_b[:1], cb_a[:1], cb_b[:1], out_a[:1], out_b[:1])
             torch.cuda.synchronize()
             lat.append(time.perf_counter() - t1)
-        p50 = sorted(lat[1:])[len(lat[1:]) // 2] * 1e3
+        p50 = sorted(lat[1:])[len(lat[1:]) // 2] * 1e3    # host-observed: submit to completion
 
     if rank == 0:
         gates = B * world * args.steps

@@ -607,46 +607,69 @@ __global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __res
   load_tables(lds_tables, tables);
   const cplx* tE = reinterpret_cast<const cplx*>(lds_tables);
   const cplx* tw = tE + 1024;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, q = lane & 31;
-  const int pair = blockIdx.x * kWavesPerBlock + wave;
-  const int ia = 2 * pair, ib = 2 * pair + 1;
-  if (ia >= B) return;
-  const bool has_b = ib < B;
   char* wave_tiles = lds + wave * wfft::kWaveBytes;
+  // persistent workgroups: the tables are loaded once per compute unit
+#pragma unroll 1
+  for (int pair = blockIdx.x * kWavesPerBlock + wave; 2 * pair < B; pair += gridDim.x * kWavesPerBlock) {
+  const int ia = 2 * pair, ib = 2 * pair + 1;
+  const bool has_b = ib < B;
 
-  double re[32], im[32], mr[32], mi[32], dar[32], dai[32], dbr[32], dbi[32];
+  double re[32], im[32];
+  unsigned park[256];      // 2 D_a and 2 D_b, parked in accumulation registers
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     re[r] = (double)d[(size_t)ia * kN + q + 32 * r];
     im[r] = has_b ? (double)d[(size_t)ib * kN + q + 32 * r] : 0.0;
   });
   wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
-  wfft::mirror2048(re, im, mr, mi, wave_tiles, q, h);
+  // With C = FFT(d_a + i d_b) and (cx, cy) = C[-k]: Ct = (cx, -cy),
+  // 2 D_a = C + Ct = (re + cx, im - cy), 2 D_b = -i (C - Ct) = (im + cy, cx - re).
+  // The mirror tile carries the real parts first, then the imaginary parts.
+  const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
+  wfft::mirror_store(re, wave_tiles, q, h);
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int p = decltype(ic)::value;
-    dar[p] = re[p] + mr[p];            // 2 D_a
-    dai[p] = im[p] + mi[p];
-    dbr[p] = im[p] - mi[p];            // 2 D_b = -i (C - Ct)
-    dbi[p] = -(re[p] - mr[p]);
+    const double cx = wfft::mirror_load<p>(ml);
+    wfft::agpr_put_f64(re[p] + cx, park[8 * p + 0], park[8 * p + 1]);
+    wfft::agpr_put_f64(cx - re[p], park[8 * p + 6], park[8 * p + 7]);
   });
+  wfft::mirror_store(im, wave_tiles, q, h);
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
+    constexpr int p = decltype(ic)::value;
+    const double cy = wfft::mirror_load<p>(ml);
+    wfft::agpr_put_f64(im[p] - cy, park[8 * p + 2], park[8 * p + 3]);
+    wfft::agpr_put_f64(im[p] + cy, park[8 * p + 4], park[8 * p + 5]);
+  });
+  wfft::wave_lds_fence();
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     re[r] = (double)s[(size_t)ia * kN + q + 32 * r];
     im[r] = has_b ? (double)s[(size_t)ib * kN + q + 32 * r] : 0.0;
   });
   wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
-  wfft::mirror2048(re, im, mr, mi, wave_tiles, q, h);
   constexpr double kScale = 1.0 / (4.0 * 2048.0);
+  double sx[32];
+  wfft::mirror_store(re, wave_tiles, q, h);
+  static_for<0, 32>([&](auto ic) WFFT_INLINE { sx[decltype(ic)::value] = wfft::mirror_load<decltype(ic)::value>(ml); });
+  wfft::mirror_store(im, wave_tiles, q, h);
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int p = decltype(ic)::value;
-    const double sar = re[p] + mr[p], sai = im[p] + mi[p];
-    const double sbr = im[p] - mi[p], sbi = -(re[p] - mr[p]);
-    const double zar = dar[p] * sar - dai[p] * sai, zai = dar[p] * sai + dai[p] * sar;
-    const double zbr = dbr[p] * sbr - dbi[p] * sbi, zbi = dbr[p] * sbi + dbi[p] * sbr;
+    const double cy = wfft::mirror_load<p>(ml);
+    const double dar = wfft::agpr_get_f64(park[8 * p + 0], park[8 * p + 1]);
+    const double dai = wfft::agpr_get_f64(park[8 * p + 2], park[8 * p + 3]);
+    const double dbr = wfft::agpr_get_f64(park[8 * p + 4], park[8 * p + 5]);
+    const double dbi = wfft::agpr_get_f64(park[8 * p + 6], park[8 * p + 7]);
+    const double sar = re[p] + sx[p], sai = im[p] - cy;
+    const double sbr = im[p] + cy, sbi = sx[p] - re[p];
+    const double zar = dar * sar - dai * sai, zai = dar * sai + dai * sar;
+    const double zbr = dbr * sbr - dbi * sbi, zbi = dbr * sbi + dbi * sbr;
     re[p] = (zar - zbi) * kScale;      // Z = Z_a + i Z_b
     im[p] = (zai + zbr) * kScale;
   });
+  wfft::wave_lds_fence();
   // Inverse transform; the second half of the outputs (t >= N) is E - twist*O.
   wfft::fft1024_inv(re, im, wave_tiles + h * wfft::kHalfBytes, tE, q);
   wfft::twist_odd_half<true>(re, im, tw, q, h);
@@ -671,6 +694,7 @@ __global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __res
       }
     }
   });
+  }
 }
 
 // Gate prologue + mod switch: x = C + wa*ca + wb*cb (wrapping, src/gates.rs,
@@ -1292,7 +1316,8 @@ int tfhe_hip_polymul_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, 
   if (!d || !s || !out) return fail(ctx, TFHE_HIP_ERR_ARG, "polynomial pointer is NULL");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t pairs = (B + 1) / 2;
-  const unsigned grid = (unsigned)((pairs + kWavesPerBlock - 1) / kWavesPerBlock);
+  const unsigned grid = (unsigned)std::min<size_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock,
+                                                   (size_t)ctx->num_cus);
   if (accumulate)
     hipLaunchKernelGGL(polymul_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (int)B);
   else

@@ -429,19 +429,6 @@ __device__ __forceinline__ double mirror_load(const MirrorLane& m) {
   return lds_load_f64(m.base, (m.wrap ? p_wrap : p_same) * 256);
 }
 
-// On entry (re, im) is a spectrum C in fwd2048's layout; on exit (mr, mi)
-// holds conj(C[-k mod 2048]) at the position of bin k.
-__device__ __forceinline__ void mirror2048(const double (&re)[32], const double (&im)[32],
-                                           double (&mr)[32], double (&mi)[32], char* wave_tiles,
-                                           int q, int h) {
-  const MirrorLane ml = mirror_lane(wave_tiles, q, h);
-  mirror_store(re, wave_tiles, q, h);
-  static_for<0, 32>([&](auto ic) WFFT_INLINE { mr[decltype(ic)::value] = mirror_load<decltype(ic)::value>(ml); });
-  mirror_store(im, wave_tiles, q, h);
-  static_for<0, 32>([&](auto ic) WFFT_INLINE { mi[decltype(ic)::value] = -mirror_load<decltype(ic)::value>(ml); });
-  wave_lds_fence();
-}
-
 // Explicit parking of long-lived values in the accumulation registers (AGPRs).
 // gfx950 has 512 registers per lane at one wave per SIMD, but vector ALU
 // instructions address only the first 256; the other 256 are reached with
