@@ -14,7 +14,10 @@ def build_library(force=False, verbose=False):
             and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in DEPS)):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC]
+    # max-ilp scheduling: one wavefront per SIMD has nobody to hide a dependent
+    # instruction's latency behind, so independent work is interleaved by the compiler
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-o", OUT, SRC]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     subprocess.check_call(cmd)
