@@ -145,7 +145,7 @@ __device__ __forceinline__ void level_product(int p, const char* tt, const cplx*
     wfft::Pipe32<4, 3, cplx> k0p;
     k0p.prologue(load_k0);
     const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
-    wfft::mirror_store(re, wave_tiles, q, h);
+    wfft::mirror_store(re, ml);
     TFHE_STAMP(st, 3);
     wfft::pipelined_for32<4, double>(
         [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
@@ -155,7 +155,7 @@ __device__ __forceinline__ void level_product(int p, const char* tt, const cplx*
           re[s] = c + ctx;                                            // Re D_0
           wfft::agpr_put_f64(ctx - c, hold[4 * s + 2], hold[4 * s + 3]);   // Im D_1
         });
-    wfft::mirror_store(im, wave_tiles, q, h);
+    wfft::mirror_store(im, ml);
     auto load_my = [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); };
     wfft::Pipe32<4, 1, double> myp;
     myp.prologue(load_my);
@@ -478,14 +478,14 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
     // with cx, my the real and imaginary part of C[-k].
     const double sa = j ? -1.0 : 1.0, sb = j ? 1.0 : -1.0;
     const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
-    wfft::mirror_store(re, wave_tiles, q, h);
+    wfft::mirror_store(re, ml);
     wfft::pipelined_for32<4, double>(
         [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
         [&](auto ic, const double& cx) WFFT_INLINE {
           constexpr int s = decltype(ic)::value;
           re[s] = re[s] * sa + cx;           // j = 0: Re D_0;  j = 1: Im D_1
         });
-    wfft::mirror_store(im, wave_tiles, q, h);
+    wfft::mirror_store(im, ml);
     wfft::pipelined_for32<4, double>(
         [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
         [&](auto ic, const double& my) WFFT_INLINE {
@@ -629,14 +629,14 @@ __global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __res
   // 2 D_a = C + Ct = (re + cx, im - cy), 2 D_b = -i (C - Ct) = (im + cy, cx - re).
   // The mirror tile carries the real parts first, then the imaginary parts.
   const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
-  wfft::mirror_store(re, wave_tiles, q, h);
+  wfft::mirror_store(re, ml);
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int p = decltype(ic)::value;
     const double cx = wfft::mirror_load<p>(ml);
     wfft::agpr_put_f64(re[p] + cx, park[8 * p + 0], park[8 * p + 1]);
     wfft::agpr_put_f64(cx - re[p], park[8 * p + 6], park[8 * p + 7]);
   });
-  wfft::mirror_store(im, wave_tiles, q, h);
+  wfft::mirror_store(im, ml);
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int p = decltype(ic)::value;
     const double cy = wfft::mirror_load<p>(ml);
@@ -652,9 +652,9 @@ __global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __res
   wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
   constexpr double kScale = 1.0 / (4.0 * 2048.0);
   double sx[32];
-  wfft::mirror_store(re, wave_tiles, q, h);
+  wfft::mirror_store(re, ml);
   static_for<0, 32>([&](auto ic) WFFT_INLINE { sx[decltype(ic)::value] = wfft::mirror_load<decltype(ic)::value>(ml); });
-  wfft::mirror_store(im, wave_tiles, q, h);
+  wfft::mirror_store(im, ml);
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int p = decltype(ic)::value;
     const double cy = wfft::mirror_load<p>(ml);

@@ -397,36 +397,40 @@ __device__ __forceinline__ void inv2048_first_half(double (&re)[32], double (&im
 }
 
 // Mirror exchange of one f64 per bin.  A spectrum in fwd2048's layout has bin
-// k = 2*(q + 32*br5(p)) + h in lane (h, q), register p; its mirror image
-// -k mod 2048 lives in the same half, at lane q2 = (32 - q) & 31 (h = 0) or
-// 31 - q (h = 1) and register 31 - p, except for lane 0 of half E where the
-// register is br5((32 - br5(p)) & 31).  mirror_store writes v to the tile,
-// mirror_load<P> then returns the value of the mirror bin of register P.
-__device__ __forceinline__ void mirror_store(const double (&v)[32], char* wave_tiles, int q, int h) {
+// k = 2*(q + 32*ka) + h in lane (h, q), register p with ka = br5(p); its mirror
+// image -k mod 2048 lives in the same half, at lane q2 = (32 - q) & 31 (h = 0)
+// or 31 - q (h = 1) and ka' = 31 - ka, except for lane 0 of half E, which is its
+// own mirror lane with ka' = (32 - ka) & 31.  mirror_store writes register p to
+// row ka of the lane's column; lane 0 of half E writes one row lower (ka = 0 to
+// row 31), so that every lane finds its mirror value at row 31 - ka of column
+// q2: all loads and all but one store are a per-lane base plus a constant.
+struct MirrorLane {
+  char* store_base;     // rows ka >= 1
+  char* store_base0;    // row of ka = 0
+  const char* load_base;
+};
+__device__ __forceinline__ MirrorLane mirror_lane(char* wave_tiles, int q, int h) {
+  MirrorLane m;
   char* tile = wave_tiles + h * kHalfBytes;
+  const bool own_mirror = (h == 0) && (q == 0);
+  m.store_base = tile + q * 8 - (own_mirror ? 256 : 0);
+  m.store_base0 = tile + q * 8 + (own_mirror ? 31 * 256 : 0);
+  const int q2 = h ? (31 - q) : ((32 - q) & 31);
+  m.load_base = tile + q2 * 8;
+  return m;
+}
+__device__ __forceinline__ void mirror_store(const double (&v)[32], const MirrorLane& m) {
   wave_lds_fence();
-  static_for<0, 32>([&](auto ic) WFFT_INLINE {
+  lds_store_f64(m.store_base0, 0, v[0]);
+  static_for<1, 32>([&](auto ic) WFFT_INLINE {
     constexpr int p = decltype(ic)::value;
-    lds_store_f64(tile, p * 256 + q * 8, v[p]);
+    lds_store_f64(m.store_base, br5(p) * 256, v[p]);
   });
   wave_lds_fence();
 }
-struct MirrorLane {
-  const char* base;   // tile + partner lane offset
-  bool wrap;          // lane 0 of half E: ka -> -ka mod 32 instead of 31 - ka
-};
-__device__ __forceinline__ MirrorLane mirror_lane(const char* wave_tiles, int q, int h) {
-  MirrorLane m;
-  const int q2 = h ? (31 - q) : ((32 - q) & 31);
-  m.base = wave_tiles + h * kHalfBytes + q2 * 8;
-  m.wrap = (h == 0) && (q == 0);
-  return m;
-}
 template <int P>
 __device__ __forceinline__ double mirror_load(const MirrorLane& m) {
-  constexpr int p_same = 31 - P;
-  constexpr int p_wrap = br5((32 - br5(P)) & 31);
-  return lds_load_f64(m.base, (m.wrap ? p_wrap : p_same) * 256);
+  return lds_load_f64(m.load_base, (31 - br5(P)) * 256);
 }
 
 // Explicit parking of long-lived values in the accumulation registers (AGPRs).
