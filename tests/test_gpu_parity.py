@@ -296,3 +296,40 @@ def test_errors_are_reported_not_thrown(eng):
     assert b"N=1024" in eng.lib.tfhe_hip_last_error(eng.ctx)
     with pytest.raises(tfhe_amd.TfheHipError):
         eng._check(rc)
+
+
+def test_abi_edge_cases():
+    """Empty batches, missing keys, NULL pointers and bad selectors come back as
+    error codes with a message (the crate panics; nothing may cross the C ABI)."""
+    import ctypes as C
+    import tfhe_amd
+    e = tfhe_amd.Engine(0)
+    try:
+        lib, ctx = e.lib, e.ctx
+        # no keys yet: state error
+        assert lib.tfhe_hip_gate(ctx, 0, None, None, None, None, None, None, None, None, None, 1) == -2
+        assert b"no keys" in lib.tfhe_hip_last_error(ctx)
+        assert lib.tfhe_hip_set_blind_rotate_mode(ctx, 7) == -1
+        P = orc.small_params(n=4)
+        K = orc.generate_synthetic_keys(P, 3)
+        _load(e, P, K)
+        # empty batch: success, pointers untouched
+        assert lib.tfhe_hip_gate(ctx, 0, None, None, None, None, None, None, None, None, None, 0) == 0
+        assert lib.tfhe_hip_bootstrap(ctx, 1 << 29, None, None, None, None, None, 0) == 0
+        assert lib.tfhe_hip_circuit_add(ctx, None, None, None, None, None, None, None, None, None, None, 0, 8) == 0
+        # NULL operands, unknown gate, mux without its third operand, negative width
+        assert lib.tfhe_hip_gate(ctx, 0, None, None, None, None, None, None, None, None, None, 1) == -1
+        a = np.zeros((1, P.n), np.int32)
+        b = np.zeros(1, np.int32)
+        pa, pb = a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p)
+        assert lib.tfhe_hip_gate(ctx, 99, pa, pb, pa, pb, None, None, pa, pb, None, 1) == -1
+        assert b"unknown gate" in lib.tfhe_hip_last_error(ctx)
+        assert lib.tfhe_hip_gate(ctx, 10, pa, pb, pa, pb, None, None, pa, pb, None, 1) == -1
+        assert lib.tfhe_hip_circuit_add(ctx, pa, pb, pa, pb, pa, pb, pa, pb, None, None, 1, -1) == -1
+        assert lib.tfhe_hip_extprod(ctx, pa, 99, pa, 1) == -1
+        # the context still works after the errors
+        oa, ob = e.gate("nand", (a, b), (a, b))
+        wa, wb, _ = orc.gate(P, "nand", K, (a[0], b[0], 0.0), (a[0], b[0], 0.0))
+        assert (oa[0] == wa).all() and ob[0] == wb
+    finally:
+        e.close()

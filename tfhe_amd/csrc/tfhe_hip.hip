@@ -719,38 +719,75 @@ __global__ void prologue_kernel(const int32_t* __restrict__ ca_a, const int32_t*
   }
 }
 
-// lwe_key_switch (src/lwe.rs:601-648).  One workgroup per ciphertext; thread v
-// owns four consecutive output coefficients (the body b is stored right after
-// the mask in each key row).  in2 (optional) and c_b implement the sum
+// lwe_key_switch (src/lwe.rs:601-648).  One workgroup per ciphertext.  Thread
+// (g, v) owns four consecutive output coefficients (the body b is stored right
+// after the mask in each key row) and walks the input coefficients i = g, g + G,
+// ...; the G partial sums meet in LDS (wrapping adds commute).  The T loads of
+// one coefficient are in flight together; digit 0, which the reference skips
+// (lwe.rs:638), is masked off (and its rows and variances are zero in the
+// packed key, so that the variance sum needs no branch).  in2 (optional) and c_b implement the sum
 // trivial(c) + u1 + u2 of the mux gate (src/gates.rs:264-266).
-__global__ __launch_bounds__(256) void keyswitch_kernel(
+constexpr int kKsBlock = 512;
+
+template <int T>   // T = ks_t when known at compile time, 0 = run-time t
+__global__ __launch_bounds__(kKsBlock) void keyswitch_kernel(
     const int32_t* __restrict__ in_a, const int32_t* __restrict__ in_b,
     const int32_t* __restrict__ in2_a, const int32_t* __restrict__ in2_b, int32_t c_b,
     int in_stride, const int32_t* __restrict__ ks_rows, const double* __restrict__ ks_var,
-    int row_stride, int n, int n_ks, int t, int32_t* __restrict__ out_a,
+    int row_stride, int n, int n_ks, int t_rt, int32_t* __restrict__ out_a,
     int32_t* __restrict__ out_b, double* __restrict__ var_out) {
+  __shared__ int32_t aibar_s[kN];
+  __shared__ int4 part[kKsBlock];
+  const int t = T ? T : t_rt;
   const int b = blockIdx.x;
-  const int v = threadIdx.x;
   const int nvec = row_stride / 4;
+  const int tpg = (nvec + 31) / 32 * 32;            // threads per group
+  const int G = kKsBlock / tpg;
+  const int g = threadIdx.x / tpg, v = threadIdx.x - g * tpg;
   const int32_t* xa = in_a + (size_t)b * in_stride;
   const int32_t* xa2 = in2_a ? in2_a + (size_t)b * in_stride : nullptr;
   const int32_t prec_offset = 1 << (32 - (1 + 2 * t));
+  for (int i = threadIdx.x; i < n_ks; i += kKsBlock) {
+    int32_t ai = xa[i];
+    if (xa2) ai = wadd(ai, xa2[i]);
+    aibar_s[i] = wadd(ai, prec_offset);
+  }
+  __syncthreads();
   uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-  if (v < nvec) {
-    for (int i = 0; i < n_ks; i++) {
-      int32_t ai = xa[i];
-      if (xa2) ai = wadd(ai, xa2[i]);
-      const int32_t aibar = wadd(ai, prec_offset);
-      for (int j = 0; j < t; j++) {
-        const int aij = (aibar >> (32 - (j + 1) * 2)) & 3;
-        if (aij != 0) {
-          const int4 row = *reinterpret_cast<const int4*>(
-              ks_rows + ((size_t)(i * t + j) * 4 + aij) * row_stride + 4 * v);
+  if (g < G && v < nvec) {
+    const int32_t* col = ks_rows + 4 * v;
+    for (int i = g; i < n_ks; i += G) {
+      const int32_t aibar = aibar_s[i];
+      if (T) {
+        int4 row[T ? T : 1];
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+          const int aij = (aibar >> (32 - (j + 1) * 2)) & 3;
+          row[j] = make_int4(0, 0, 0, 0);
+          if (aij != 0)      // digit 0 costs no memory traffic
+            row[j] = *reinterpret_cast<const int4*>(col + ((size_t)(i * T + j) * 4 + aij) * row_stride);
+        }
+#pragma unroll
+        for (int j = 0; j < T; j++) {
+          a0 -= (uint32_t)row[j].x; a1 -= (uint32_t)row[j].y; a2 -= (uint32_t)row[j].z; a3 -= (uint32_t)row[j].w;
+        }
+      } else {
+        for (int j = 0; j < t; j++) {
+          const int aij = (aibar >> (32 - (j + 1) * 2)) & 3;
+          const int4 row = *reinterpret_cast<const int4*>(col + ((size_t)(i * t + j) * 4 + aij) * row_stride);
           a0 -= (uint32_t)row.x; a1 -= (uint32_t)row.y; a2 -= (uint32_t)row.z; a3 -= (uint32_t)row.w;
         }
       }
     }
-    uint32_t acc4[4] = {a0, a1, a2, a3};
+  }
+  part[threadIdx.x] = make_int4((int)a0, (int)a1, (int)a2, (int)a3);
+  __syncthreads();
+  if (g == 0 && v < nvec) {
+    for (int k = 1; k < G; k++) {
+      const int4 o = part[k * tpg + v];
+      a0 += (uint32_t)o.x; a1 += (uint32_t)o.y; a2 += (uint32_t)o.z; a3 += (uint32_t)o.w;
+    }
+    const uint32_t acc4[4] = {a0, a1, a2, a3};
     for (int e = 0; e < 4; e++) {
       const int x = 4 * v + e;
       if (x < n) out_a[(size_t)b * n + x] = (int32_t)acc4[e];
@@ -761,34 +798,40 @@ __global__ __launch_bounds__(256) void keyswitch_kernel(
       }
     }
   }
-  if (var_out && v == 0) {
-    double var = 0.0;       // summed in the reference's order, lwe.rs:109
+  if (var_out && threadIdx.x == kKsBlock - 1) {
+    // summed in the reference's order (lwe.rs:109); the entries of digit 0 are +0.0
+    double var = 0.0;
     for (int i = 0; i < n_ks; i++) {
-      int32_t ai = xa[i];
-      if (xa2) ai = wadd(ai, xa2[i]);
-      const int32_t aibar = wadd(ai, prec_offset);
-      for (int j = 0; j < t; j++) {
-        const int aij = (aibar >> (32 - (j + 1) * 2)) & 3;
-        if (aij != 0) var += ks_var[(size_t)(i * t + j) * 4 + aij];
-      }
+      const int32_t aibar = aibar_s[i];
+      const double* vi = ks_var + (size_t)i * t * 4;
+#pragma unroll 8
+      for (int j = 0; j < t; j++) var += vi[j * 4 + ((aibar >> (32 - (j + 1) * 2)) & 3)];
     }
     var_out[b] = var;
   }
 }
 
-// Packs the key-switch key into rows [a_0 .. a_{n-1}, b, 0 pad] of row_stride int32.
 __global__ void fill_kernel(int32_t* __restrict__ p, int32_t v, size_t count) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) p[i] = v;
 }
 
+// Packs the key-switch key into rows [a_0 .. a_{n-1}, b, 0 pad] of row_stride
+// int32; the rows of digit 0 (row index = 0 mod 4), which lwe.rs:638 never
+// reads, become zero.  ks_var_zero_kernel does the same to their variances.
 __global__ void ks_pack_kernel(const int32_t* __restrict__ ks_a, const int32_t* __restrict__ ks_b,
                                int n, int row_stride, size_t rows, int32_t* __restrict__ dst) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * (size_t)row_stride) return;
   const size_t row = idx / row_stride;
   const int x = (int)(idx - row * row_stride);
-  dst[idx] = x < n ? ks_a[row * n + x] : (x == n ? ks_b[row] : 0);
+  const int32_t val = x < n ? ks_a[row * n + x] : (x == n ? ks_b[row] : 0);
+  dst[idx] = (row & 3) == 0 ? 0 : val;
+}
+
+__global__ void ks_var_zero_kernel(double* __restrict__ var, size_t rows) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i < rows) var[i] = 0.0;
 }
 
 }  // namespace
@@ -990,9 +1033,14 @@ int launch_keyswitch(tfhe_hip_ctx* ctx, const int32_t* in_a, const int32_t* in_b
                      double* var_out, size_t B) {
   const double* ks_var = (const double*)(ctx->ksblob + ctx->ks_rows_bytes);
   ProfileScope prof(ctx, 2);
-  hipLaunchKernelGGL(keyswitch_kernel, dim3((unsigned)B), dim3(256), 0, ctx->stream, in_a, in_b, in2_a,
-                     in2_b, c_b, kN, (const int32_t*)ctx->ksblob, ks_var, ctx->row_stride, ctx->P.n,
-                     ctx->P.n_ks, ctx->P.ks_t, out_a, out_b, var_out);
+  if (ctx->P.ks_t == 8)
+    hipLaunchKernelGGL(keyswitch_kernel<8>, dim3((unsigned)B), dim3(kKsBlock), 0, ctx->stream, in_a, in_b,
+                       in2_a, in2_b, c_b, kN, (const int32_t*)ctx->ksblob, ks_var, ctx->row_stride,
+                       ctx->P.n, ctx->P.n_ks, ctx->P.ks_t, out_a, out_b, var_out);
+  else
+    hipLaunchKernelGGL(keyswitch_kernel<0>, dim3((unsigned)B), dim3(kKsBlock), 0, ctx->stream, in_a, in_b,
+                       in2_a, in2_b, c_b, kN, (const int32_t*)ctx->ksblob, ks_var, ctx->row_stride,
+                       ctx->P.n, ctx->P.n_ks, ctx->P.ks_t, out_a, out_b, var_out);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
@@ -1221,6 +1269,9 @@ int tfhe_hip_load_keys(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, const i
                                   hipMemcpyHostToDevice, ctx->stream));
     else
       HIP_TRY(ctx, hipMemsetAsync(ctx->ksblob + ctx->ks_rows_bytes, 0, rows * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(ks_var_zero_kernel, dim3((unsigned)((rows / 4 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (double*)(ctx->ksblob + ctx->ks_rows_bytes), rows);
+    HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   }
   ctx->have_keys = true;
