@@ -60,6 +60,29 @@ def synthetic_keys(level, seed):
                 ks_var=rng.random((n, 8, 4)) * 1e-9)
 
 
+def reference_style_keys(level, seed):
+    """Keys with the structure the crate's generate_keys produces (src/lwe.rs:474-558,
+    src/tgsw.rs:118-167): in every TGSW sample only the rows of decomposition level 0 are
+    encrypted (uniform mask, one Gaussian coefficient in the body's first N entries) and
+    the secret bit times l is added to coefficient 0 of each polynomial; key-switch
+    entries of digit 0 are zero.  Used to show that throughput does not depend on the key
+    material (the kernels are data independent)."""
+    p = LEVELS[level]
+    rng = np.random.default_rng(seed)
+    n, l = p["n"], p["l"]
+    key = rng.integers(0, 2, size=n, dtype=np.int64)
+    bk = np.zeros((n, l, 2, 2, 1024), dtype=np.int64)
+    bk[:, 0, :, 0, :] = rng.integers(-2**31, 2**31, size=(n, 2, 1024))
+    bk[:, 0, :, 1, 1023] = np.rint(rng.normal(0.0, 9.0e-9 * 2.0**32, size=(n, 2)))
+    bk[:, 0, :, :, 0] += (key * l)[:, None, None]
+    ks_a = rng.integers(-2**31, 2**31, size=(n, 8, 4, n), dtype=np.int64)
+    ks_b = rng.integers(-2**31, 2**31, size=(n, 8, 4), dtype=np.int64)
+    ks_var = np.full((n, 8, 4), 1e-10)
+    ks_a[:, :, 0], ks_b[:, :, 0], ks_var[:, :, 0] = 0, 0, 0.0
+    wrap = lambda x: ((x + 2**31) % 2**32 - 2**31).astype(np.int32)
+    return dict(bk=wrap(bk), ks_a=wrap(ks_a), ks_b=wrap(ks_b), ks_var=ks_var)
+
+
 def measured_traffic(level, batch):
     """HBM-side bytes per blind-rotate launch from the committed PMC passes
     (profiles/r01_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this very
@@ -203,6 +226,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--workload", default="nand", choices=["nand", "add32", "polymul"])
+    ap.add_argument("--keys", default="synthetic", choices=["synthetic", "reference"],
+                    help="synthetic: every key entry uniform (no stage degenerates); reference: "
+                         "the structure the crate's generate_keys produces")
     args = ap.parse_args()
     if args.workload != "nand":
         return side_workload(args)
@@ -230,7 +256,7 @@ def main():
 
     # keys: rank 0 loads and transforms, the device blobs are broadcast once
     if rank == 0:
-        K = synthetic_keys(args.level, 0xC0FFEE + 3)
+        K = (synthetic_keys if args.keys == "synthetic" else reference_style_keys)(args.level, 0xC0FFEE + 3)
         eng.load_keys(params, K["bk"], K["ks_a"], K["ks_b"], K["ks_var"])
     if world > 1:
         from tfhe_amd import parallel
@@ -302,7 +328,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"batched bootstrapped NAND, {B} gates per GPU per step, "
                                    f"Bit{args.level} (n={lv['n']}, N=1024, k=1, l={lv['l']}, "
-                                   f"Bg=2^{lv['bg_bit']}, ks t=8 base=4), keys resident in HBM",
+                                   f"Bg=2^{lv['bg_bit']}, ks t=8 base=4), {args.keys} keys resident in HBM",
                        "batch_per_gpu": B, "security_level": args.level,
                        "parallelism": f"batch sharded over {world} GPU(s), keys replicated"},
             "p50_single_gate_latency_ms": p50,
