@@ -52,6 +52,15 @@ struct StampCtx {
 #define TFHE_STAMP(ctx, k) ((void)0)
 #endif
 
+// Depth (in groups of four 16-byte loads) of the software pipelines that fetch
+// the two key columns of a level; tuned on MI355X.
+#ifndef TFHE_K0_DEPTH
+#define TFHE_K0_DEPTH 4
+#endif
+#ifndef TFHE_K1_DEPTH
+#define TFHE_K1_DEPTH 3
+#endif
+
 namespace {
 
 constexpr int kN = 1024;
@@ -142,7 +151,7 @@ __device__ __forceinline__ void level_product(int p, const char* tt, const cplx*
     // Z_0 = D_0 * key_0 in place; D_1 is parked.  The first loads of key
     // column 0 are issued before the mirror passes.  Real parts go through
     // the tile first, then the imaginary parts.
-    wfft::Pipe32<4, 3, cplx> k0p;
+    wfft::Pipe32<4, TFHE_K0_DEPTH, cplx> k0p;
     k0p.prologue(load_k0);
     const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
     wfft::mirror_store(re, ml);
@@ -161,10 +170,11 @@ __device__ __forceinline__ void level_product(int p, const char* tt, const cplx*
     myp.prologue(load_my);
     static_for<0, 8>([&](auto gc) WFFT_INLINE {
       constexpr int g = decltype(gc)::value;
-      if constexpr (g + 3 < 8) {
+      if constexpr (g + TFHE_K0_DEPTH < 8) {
         static_for<0, 4>([&](auto ic) WFFT_INLINE {
           constexpr int e = decltype(ic)::value;
-          k0p.buf[(g + 3) % 4][e] = load_k0(std::integral_constant<int, (g + 3) * 4 + e>{});
+          k0p.buf[(g + TFHE_K0_DEPTH) % (TFHE_K0_DEPTH + 1)][e] =
+              load_k0(std::integral_constant<int, (g + TFHE_K0_DEPTH) * 4 + e>{});
         });
       }
       if constexpr (g + 1 < 8) {
@@ -177,7 +187,7 @@ __device__ __forceinline__ void level_product(int p, const char* tt, const cplx*
         constexpr int e = decltype(ic)::value;
         constexpr int s = g * 4 + e;
         const double my = myp.buf[g % 2][e];          // Im C[-k]; Ct = (.., -my)
-        const cplx ka = k0p.buf[g % 4][e];
+        const cplx ka = k0p.buf[g % (TFHE_K0_DEPTH + 1)][e];
         const double d0r = re[s], d0i = im[s] - my;
         wfft::agpr_put_f64(im[s] + my, hold[4 * s + 0], hold[4 * s + 1]);   // Re D_1
         re[s] = d0r * ka.x - d0i * ka.y;
@@ -191,7 +201,7 @@ __device__ __forceinline__ void level_product(int p, const char* tt, const cplx*
   TFHE_STAMP(st, 5);
   {
     // Z_1 = D_1 * key_1 as D_1 comes back from the accumulation registers.
-    wfft::Pipe32<4, 3, cplx> k1p;
+    wfft::Pipe32<4, TFHE_K1_DEPTH, cplx> k1p;
     k1p.prologue(load_k1);
     k1p.run(load_k1, [&](auto ic, const cplx& kb) WFFT_INLINE {
       constexpr int s = decltype(ic)::value;
@@ -672,7 +682,7 @@ __global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __res
   wfft::wave_lds_fence();
   // Inverse transform; the second half of the outputs (t >= N) is E - twist*O.
   wfft::fft1024_inv(re, im, wave_tiles + h * wfft::kHalfBytes, tE, q);
-  wfft::twist_odd_half<true>(re, im, tw, q, h);
+  wfft::twist_odd_half<true>(re, im, tE, tw, q, h);
   const int prod = h ? ib : ia;        // half E ends with product a, half O with product b
   const bool live = h ? has_b : true;
   static_for<0, 32>([&](auto ic) WFFT_INLINE {

@@ -31,6 +31,19 @@
 
 #include <type_traits>
 
+// Group size of the software pipelines that fetch twiddles from LDS (tuned).
+#ifndef WFFT_TW_GROUP
+#define WFFT_TW_GROUP 8
+#endif
+#ifndef WFFT_TWIST_GROUP
+#define WFFT_TWIST_GROUP 4
+#endif
+// 1: the twist of the odd half-wave runs without a branch (the even half
+// multiplies by 1); 0: under a branch on the half.
+#ifndef WFFT_TWIST_BRANCHFREE
+#define WFFT_TWIST_BRANCHFREE 0
+#endif
+
 namespace wfft {
 
 constexpr int kN = 1024;           // polynomial size
@@ -274,7 +287,7 @@ __device__ __forceinline__ void fft1024_fwd(double (&re)[32], double (&im)[32], 
   // twiddle; the real parts leave for the tile at once, the imaginary parts
   // follow when the real parts have come back (same tile, program order).
   wave_lds_fence();
-  pipelined_for32<4, cplx>(
+  pipelined_for32<WFFT_TW_GROUP, cplx>(
       [&](auto ic) WFFT_INLINE { return tE[br5(decltype(ic)::value) * 32 + q]; },
       [&](auto ic, const cplx& w) WFFT_INLINE {
         constexpr int p = decltype(ic)::value;
@@ -298,7 +311,7 @@ __device__ __forceinline__ void fft1024_inv(double (&re)[32], double (&im)[32], 
                                             const cplx* tE, int q) {
   dit32<true>(re, im);
   wave_lds_fence();
-  pipelined_for32<4, cplx>(
+  pipelined_for32<WFFT_TW_GROUP, cplx>(
       [&](auto ic) WFFT_INLINE { return tE[decltype(ic)::value * 32 + q]; },
       [&](auto ic, const cplx& w) WFFT_INLINE {
         constexpr int kb = decltype(ic)::value;
@@ -319,23 +332,32 @@ __device__ __forceinline__ void fft1024_inv(double (&re)[32], double (&im)[32], 
 // Multiply the O half by the twist w2048^(q + 32 r) (CONJ: by its conjugate).
 // tw: LDS table, entry [r*32 + q] = exp(-2 pi i (q + 32 r) / 2048).  natural layout.
 template <bool CONJ>
-__device__ __forceinline__ void twist_odd_half(double (&re)[32], double (&im)[32], const cplx* tw,
-                                               int q, int h) {
+__device__ __forceinline__ void twist_odd_half(double (&re)[32], double (&im)[32], const cplx* tE,
+                                               const cplx* tw, int q, int h) {
+  auto mul = [&](auto ic, const cplx& w) WFFT_INLINE {
+    constexpr int r = decltype(ic)::value;
+    const double xr = re[r], xi = im[r];
+    if constexpr (!CONJ) {
+      re[r] = xr * w.x - xi * w.y;
+      im[r] = xr * w.y + xi * w.x;
+    } else {
+      re[r] = xr * w.x + xi * w.y;
+      im[r] = xi * w.x - xr * w.y;
+    }
+  };
+#if WFFT_TWIST_BRANCHFREE
+  // The E half multiplies by 1, read from column 0 of tE (tE[r*32] = w1024^0);
+  // x * (1 + 0i) is exact.
+  const cplx* w_lane = h ? tw + q : tE;
+  pipelined_for32<WFFT_TWIST_GROUP, cplx>(
+      [&](auto ic) WFFT_INLINE { return w_lane[decltype(ic)::value * 32]; }, mul);
+#else
+  (void)tE;
   if (h) {
-    pipelined_for32<4, cplx>(
-        [&](auto ic) WFFT_INLINE { return tw[decltype(ic)::value * 32 + q]; },
-        [&](auto ic, const cplx& w) WFFT_INLINE {
-          constexpr int r = decltype(ic)::value;
-          const double xr = re[r], xi = im[r];
-          if constexpr (!CONJ) {
-            re[r] = xr * w.x - xi * w.y;
-            im[r] = xr * w.y + xi * w.x;
-          } else {
-            re[r] = xr * w.x + xi * w.y;
-            im[r] = xi * w.x - xr * w.y;
-          }
-        });
+    pipelined_for32<WFFT_TWIST_GROUP, cplx>(
+        [&](auto ic) WFFT_INLINE { return tw[decltype(ic)::value * 32 + q]; }, mul);
   }
+#endif
 }
 
 // Zero-padded 2048-point forward transform of c[n] = re + i im (n < 1024),
@@ -343,7 +365,7 @@ __device__ __forceinline__ void twist_odd_half(double (&re)[32], double (&im)[32
 // On exit lane (h, q), register p holds bin k = 2*(q + 32*br5(p)) + h.
 __device__ __forceinline__ void fwd2048(double (&re)[32], double (&im)[32], char* wave_tiles,
                                         const cplx* tE, const cplx* tw, int q, int h) {
-  twist_odd_half<false>(re, im, tw, q, h);
+  twist_odd_half<false>(re, im, tE, tw, q, h);
   fft1024_fwd(re, im, wave_tiles + h * kHalfBytes, tE, q);
 }
 
@@ -386,7 +408,7 @@ __device__ __forceinline__ void inv2048_first_half(double (&re)[32], double (&im
                                                    Mid&& mid) {
   fft1024_inv(re, im, wave_tiles + h * kHalfBytes, tE, q);
   mid();
-  twist_odd_half<true>(re, im, tw, q, h);
+  twist_odd_half<true>(re, im, tE, tw, q, h);
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     // (E: Re E | O: Im E) + (E: Re twO | O: Im twO)
