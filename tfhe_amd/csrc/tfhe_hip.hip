@@ -57,6 +57,9 @@ struct StampCtx {
 #ifndef TFHE_K0_DEPTH
 #define TFHE_K0_DEPTH 4
 #endif
+#ifndef TFHE_MIRROR_GROUP
+#define TFHE_MIRROR_GROUP 4
+#endif
 #ifndef TFHE_K1_DEPTH
 #define TFHE_K1_DEPTH 3
 #endif
@@ -156,7 +159,7 @@ __device__ __forceinline__ void level_product(int p, const char* tt, const cplx*
     const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
     wfft::mirror_store(re, ml);
     TFHE_STAMP(st, 3);
-    wfft::pipelined_for32<4, double>(
+    wfft::pipelined_for32<TFHE_MIRROR_GROUP, double>(
         [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
         [&](auto ic, const double& ctx) WFFT_INLINE {
           constexpr int s = decltype(ic)::value;

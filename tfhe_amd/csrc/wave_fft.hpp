@@ -40,6 +40,15 @@
 #endif
 // 1: the twist of the odd half-wave runs without a branch (the even half
 // multiplies by 1); 0: under a branch on the half.
+// Scheduling fences: between the groups of a software pipeline (1/0), and
+// every WFFT_TAIL_CHUNK elements of the inverse transform's element-wise tail
+// (0 = none).
+#ifndef WFFT_PIPE_BARRIER
+#define WFFT_PIPE_BARRIER 1
+#endif
+#ifndef WFFT_TAIL_CHUNK
+#define WFFT_TAIL_CHUNK 0
+#endif
 #ifndef WFFT_TWIST_BRANCHFREE
 #define WFFT_TWIST_BRANCHFREE 0
 #endif
@@ -113,7 +122,9 @@ struct Pipe32 {
         constexpr int e = decltype(ic)::value;
         use(std::integral_constant<int, g * G + e>{}, buf[g % (D + 1)][e]);
       });
+#if WFFT_PIPE_BARRIER
       __builtin_amdgcn_sched_barrier(0);
+#endif
     });
   }
 };
@@ -409,13 +420,18 @@ __device__ __forceinline__ void inv2048_first_half(double (&re)[32], double (&im
   fft1024_inv(re, im, wave_tiles + h * kHalfBytes, tE, q);
   mid();
   twist_odd_half<true>(re, im, tE, tw, q, h);
-  static_for<0, 32>([&](auto ic) WFFT_INLINE {
+  auto tail = [&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     // (E: Re E | O: Im E) + (E: Re twO | O: Im twO)
     double a = re[r], b = im[r];
     swap_halves(a, b);
     sink(ic, a + b);
-  });
+  };
+#if WFFT_TAIL_CHUNK
+  chunked_for32<WFFT_TAIL_CHUNK>(tail);
+#else
+  static_for<0, 32>(tail);
+#endif
 }
 
 // Mirror exchange of one f64 per bin.  A spectrum in fwd2048's layout has bin
