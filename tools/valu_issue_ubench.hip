@@ -3,12 +3,13 @@
 // Measured on MI355X (clock64 ticks, 2.4 GHz): distance 1: 8.5, 2: 6.4, 3: 5.9, 4: 5.6, >= 6: 5.2-5.4.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-template <int D, int OP>
+template <int D, int OP, bool HALF_WAVE = false>
 __global__ __launch_bounds__(256, 1) void k(unsigned long long* out, double seed, int iters) {
   double x[16];
   for (int i = 0; i < 16; i++) x[i] = seed + i + threadIdx.x;
   double w = 1.0000001, z = 0.5;
   unsigned long long t0 = clock64();
+  if (!HALF_WAVE || (threadIdx.x & 32))       // HALF_WAVE: only lanes 32-63 of each wavefront run the loop
   for (int it = 0; it < iters; it++) {
 #pragma unroll
     for (int rep = 0; rep < 48 / D; rep++) {
@@ -22,15 +23,15 @@ __global__ __launch_bounds__(256, 1) void k(unsigned long long* out, double seed
     }
   }
   unsigned long long t1 = clock64();
-  if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = t1 - t0;
+  if (threadIdx.x == 32 && blockIdx.x == 0) out[0] = t1 - t0;
   double s = 0; for (int i = 0; i < 16; i++) s += x[i];
   if (s == 12345.678) out[1] = 1;
 }
-template <int D, int OP> void run(unsigned long long* d) {
+template <int D, int OP, bool HALF_WAVE = false> void run(unsigned long long* d) {
   unsigned long long h[2];
   const int iters = 256;
-  k<D, OP><<<1, 256>>>(d, 1.0, iters);
-  k<D, OP><<<1, 256>>>(d, 1.0, iters);
+  k<D, OP, HALF_WAVE><<<1, 256>>>(d, 1.0, iters);
+  k<D, OP, HALF_WAVE><<<1, 256>>>(d, 1.0, iters);
   hipMemcpy(h, d, 16, hipMemcpyDeviceToHost);
   printf(" %5.2f", (double)h[0] / (iters * (48 / D) * D));
 }
@@ -46,5 +47,9 @@ int main() {
   row<1>("v_fma_f64 (src0 dep)", d);
   row<2>("v_fma_f64 (src2 dep)", d);
   row<3>("v_mul_f64 (src0 dep)", d);
+  printf("%-28s", "v_fma_f64, lanes 32-63 only");
+  run<1, 1, true>(d); run<2, 1, true>(d); run<3, 1, true>(d); run<4, 1, true>(d); run<6, 1, true>(d); run<8, 1, true>(d);
+  run<12, 1, true>(d); run<16, 1, true>(d);
+  printf("\n");
   return 0;
 }
