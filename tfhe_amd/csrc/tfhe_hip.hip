@@ -58,10 +58,10 @@ struct StampCtx {
 #define TFHE_K0_DEPTH 4
 #endif
 #ifndef TFHE_MIRROR_GROUP
-#define TFHE_MIRROR_GROUP 4
+#define TFHE_MIRROR_GROUP 8
 #endif
 #ifndef TFHE_K1_DEPTH
-#define TFHE_K1_DEPTH 3
+#define TFHE_K1_DEPTH 4
 #endif
 
 namespace {
@@ -190,11 +190,14 @@ __device__ __forceinline__ void level_product(int p, const char* tt, const cplx*
         constexpr int e = decltype(ic)::value;
         constexpr int s = g * 4 + e;
         const double my = myp.buf[g % 2][e];          // Im C[-k]; Ct = (.., -my)
-        const cplx ka = k0p.buf[g % (TFHE_K0_DEPTH + 1)][e];
-        const double d0r = re[s], d0i = im[s] - my;
         wfft::agpr_put_f64(im[s] + my, hold[4 * s + 0], hold[4 * s + 1]);   // Re D_1
-        re[s] = d0r * ka.x - d0i * ka.y;
-        im[s] = d0r * ka.y + d0i * ka.x;
+        im[s] = im[s] - my;                                                 // Im D_0
+      });
+      static_for<0, 2>([&](auto ic) WFFT_INLINE {
+        constexpr int e = 2 * decltype(ic)::value;
+        constexpr int s = g * 4 + e;
+        wfft::cmul2<false>(re[s], im[s], k0p.buf[g % (TFHE_K0_DEPTH + 1)][e], re[s + 1], im[s + 1],
+                           k0p.buf[g % (TFHE_K0_DEPTH + 1)][e + 1]);
       });
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -206,12 +209,13 @@ __device__ __forceinline__ void level_product(int p, const char* tt, const cplx*
     // Z_1 = D_1 * key_1 as D_1 comes back from the accumulation registers.
     wfft::Pipe32<4, TFHE_K1_DEPTH, cplx> k1p;
     k1p.prologue(load_k1);
-    k1p.run(load_k1, [&](auto ic, const cplx& kb) WFFT_INLINE {
-      constexpr int s = decltype(ic)::value;
-      const double d1r = wfft::agpr_get_f64(hold[4 * s + 0], hold[4 * s + 1]);
-      const double d1i = wfft::agpr_get_f64(hold[4 * s + 2], hold[4 * s + 3]);
-      re[s] = d1r * kb.x - d1i * kb.y;
-      im[s] = d1r * kb.y + d1i * kb.x;
+    k1p.run2(load_k1, [&](auto i0, const cplx& ka, auto i1, const cplx& kb) WFFT_INLINE {
+      constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;
+      re[s0] = wfft::agpr_get_f64(hold[4 * s0 + 0], hold[4 * s0 + 1]);
+      im[s0] = wfft::agpr_get_f64(hold[4 * s0 + 2], hold[4 * s0 + 3]);
+      re[s1] = wfft::agpr_get_f64(hold[4 * s1 + 0], hold[4 * s1 + 1]);
+      im[s1] = wfft::agpr_get_f64(hold[4 * s1 + 2], hold[4 * s1 + 3]);
+      wfft::cmul2<false>(re[s0], im[s0], ka, re[s1], im[s1], kb);
     });
   }
   TFHE_STAMP(st, 6);

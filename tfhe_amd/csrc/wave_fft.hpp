@@ -108,6 +108,28 @@ struct Pipe32 {
       buf[i / G][i % G] = load(ic);
     });
   }
+  // As run, but use2(i, value_i, i + 1, value_{i+1}) takes two consecutive elements.
+  template <class LoadF, class Use2F>
+  __device__ __forceinline__ void run2(LoadF&& load, Use2F&& use2) {
+    static_assert(G % 2 == 0, "pairs");
+    static_for<0, 32 / G>([&](auto gc) WFFT_INLINE {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (g + D < 32 / G) {
+        static_for<0, G>([&](auto ic) WFFT_INLINE {
+          constexpr int e = decltype(ic)::value;
+          buf[(g + D) % (D + 1)][e] = load(std::integral_constant<int, (g + D) * G + e>{});
+        });
+      }
+      static_for<0, G / 2>([&](auto ic) WFFT_INLINE {
+        constexpr int e = 2 * decltype(ic)::value;
+        use2(std::integral_constant<int, g * G + e>{}, buf[g % (D + 1)][e],
+             std::integral_constant<int, g * G + e + 1>{}, buf[g % (D + 1)][e + 1]);
+      });
+#if WFFT_PIPE_BARRIER
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    });
+  }
   template <class LoadF, class UseF>
   __device__ __forceinline__ void run(LoadF&& load, UseF&& use) {
     static_for<0, 32 / G>([&](auto gc) WFFT_INLINE {
@@ -128,6 +150,15 @@ struct Pipe32 {
     });
   }
 };
+
+// As pipelined_for32, but use2(i, value_i, i + 1, value_{i+1}) takes two
+// consecutive elements at a time.
+template <int G, class T, class LoadF, class Use2F>
+__device__ __forceinline__ void pipelined_pairs32(LoadF&& load, Use2F&& use2) {
+  Pipe32<G, 1, T> pipe;
+  pipe.prologue(load);
+  pipe.run2(load, use2);
+}
 
 template <int G, class T, class LoadF, class UseF>
 __device__ __forceinline__ void pipelined_for32(LoadF&& load, UseF&& use) {
@@ -178,6 +209,29 @@ __device__ __forceinline__ void mul_w32(double dr, double di, double& outr, doub
     outr = dr * c - di * s;
     outi = dr * s + di * c;
   }
+}
+
+// Two complex products x <- x * w (CONJ: x * conj(w)) with the four
+// multiplications issued before the four fused multiply-adds that consume
+// them: a vector instruction whose operand was produced by the instruction
+// right before it issues 3 clocks late on a SIMD that runs a single wavefront,
+// and the compiler pairs each multiplication with its consumer.
+template <bool CONJ>
+__device__ __forceinline__ void cmul2(double& ar, double& ai, const cplx& wa, double& br, double& bi,
+                                      const cplx& wb) {
+  double t0, t1, t2, t3;
+  if constexpr (!CONJ)
+    asm("v_mul_f64 %4, %1, %9\n\tv_mul_f64 %5, %0, %9\n\tv_mul_f64 %6, %3, %11\n\tv_mul_f64 %7, %2, %11\n\t"
+        "v_fma_f64 %0, %0, %8, -%4\n\tv_fma_f64 %1, %1, %8, %5\n\t"
+        "v_fma_f64 %2, %2, %10, -%6\n\tv_fma_f64 %3, %3, %10, %7"
+        : "+v"(ar), "+v"(ai), "+v"(br), "+v"(bi), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(wa.x), "v"(wa.y), "v"(wb.x), "v"(wb.y));
+  else
+    asm("v_mul_f64 %4, %1, %9\n\tv_mul_f64 %5, %0, %9\n\tv_mul_f64 %6, %3, %11\n\tv_mul_f64 %7, %2, %11\n\t"
+        "v_fma_f64 %0, %0, %8, %4\n\tv_fma_f64 %1, %1, %8, -%5\n\t"
+        "v_fma_f64 %2, %2, %10, %6\n\tv_fma_f64 %3, %3, %10, -%7"
+        : "+v"(ar), "+v"(ai), "+v"(br), "+v"(bi), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(wa.x), "v"(wa.y), "v"(wb.x), "v"(wb.y));
 }
 
 // Decimation in frequency, natural in -> bit-reversed out.
@@ -298,19 +352,13 @@ __device__ __forceinline__ void fft1024_fwd(double (&re)[32], double (&im)[32], 
   // twiddle; the real parts leave for the tile at once, the imaginary parts
   // follow when the real parts have come back (same tile, program order).
   wave_lds_fence();
-  pipelined_for32<WFFT_TW_GROUP, cplx>(
+  pipelined_pairs32<WFFT_TW_GROUP, cplx>(
       [&](auto ic) WFFT_INLINE { return tE[br5(decltype(ic)::value) * 32 + q]; },
-      [&](auto ic, const cplx& w) WFFT_INLINE {
-        constexpr int p = decltype(ic)::value;
-        constexpr int kb = br5(p);
-        double xr = re[p], xi = im[p];
-        if constexpr (kb != 0) {
-          const double yr = xr * w.x - xi * w.y;
-          xi = xr * w.y + xi * w.x;
-          xr = yr;
-        }
-        im[p] = xi;
-        transpose_store<kb>(tile, q, xr);
+      [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
+        constexpr int p0 = decltype(i0)::value, p1 = decltype(i1)::value;
+        cmul2<false>(re[p0], im[p0], w0, re[p1], im[p1], w1);      // register 0 takes w = 1
+        transpose_store<br5(p0)>(tile, q, re[p0]);
+        transpose_store<br5(p1)>(tile, q, re[p1]);
       });
   transpose_load<false, true>(re, tile, q);
   transpose_f64<true, false, true>(im, tile, q);
@@ -322,18 +370,13 @@ __device__ __forceinline__ void fft1024_inv(double (&re)[32], double (&im)[32], 
                                             const cplx* tE, int q) {
   dit32<true>(re, im);
   wave_lds_fence();
-  pipelined_for32<WFFT_TW_GROUP, cplx>(
+  pipelined_pairs32<WFFT_TW_GROUP, cplx>(
       [&](auto ic) WFFT_INLINE { return tE[decltype(ic)::value * 32 + q]; },
-      [&](auto ic, const cplx& w) WFFT_INLINE {
-        constexpr int kb = decltype(ic)::value;
-        double xr = re[kb], xi = im[kb];
-        if constexpr (kb != 0) {                       // conjugate twiddle
-          const double yr = xr * w.x + xi * w.y;
-          xi = xi * w.x - xr * w.y;
-          xr = yr;
-        }
-        im[kb] = xi;
-        transpose_store<kb>(tile, q, xr);
+      [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
+        constexpr int k0 = decltype(i0)::value, k1 = decltype(i1)::value;
+        cmul2<true>(re[k0], im[k0], w0, re[k1], im[k1], w1);       // conjugate twiddle
+        transpose_store<k0>(tile, q, re[k0]);
+        transpose_store<k1>(tile, q, re[k1]);
       });
   transpose_load<true, false>(re, tile, q);
   transpose_f64<false, true, false>(im, tile, q);
@@ -345,27 +388,20 @@ __device__ __forceinline__ void fft1024_inv(double (&re)[32], double (&im)[32], 
 template <bool CONJ>
 __device__ __forceinline__ void twist_odd_half(double (&re)[32], double (&im)[32], const cplx* tE,
                                                const cplx* tw, int q, int h) {
-  auto mul = [&](auto ic, const cplx& w) WFFT_INLINE {
-    constexpr int r = decltype(ic)::value;
-    const double xr = re[r], xi = im[r];
-    if constexpr (!CONJ) {
-      re[r] = xr * w.x - xi * w.y;
-      im[r] = xr * w.y + xi * w.x;
-    } else {
-      re[r] = xr * w.x + xi * w.y;
-      im[r] = xi * w.x - xr * w.y;
-    }
+  auto mul = [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
+    constexpr int r0 = decltype(i0)::value, r1 = decltype(i1)::value;
+    cmul2<CONJ>(re[r0], im[r0], w0, re[r1], im[r1], w1);
   };
 #if WFFT_TWIST_BRANCHFREE
   // The E half multiplies by 1, read from column 0 of tE (tE[r*32] = w1024^0);
   // x * (1 + 0i) is exact.
   const cplx* w_lane = h ? tw + q : tE;
-  pipelined_for32<WFFT_TWIST_GROUP, cplx>(
+  pipelined_pairs32<WFFT_TWIST_GROUP, cplx>(
       [&](auto ic) WFFT_INLINE { return w_lane[decltype(ic)::value * 32]; }, mul);
 #else
   (void)tE;
   if (h) {
-    pipelined_for32<WFFT_TWIST_GROUP, cplx>(
+    pipelined_pairs32<WFFT_TWIST_GROUP, cplx>(
         [&](auto ic) WFFT_INLINE { return tw[decltype(ic)::value * 32 + q]; }, mul);
   }
 #endif
