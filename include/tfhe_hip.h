@@ -54,7 +54,9 @@ enum {
   TFHE_HIP_ANDNY, TFHE_HIP_ANDYN, TFHE_HIP_ORNY, TFHE_HIP_ORYN, TFHE_HIP_MUX
 };
 
-/* Creates a context on GPU `device`. */
+/* Creates a context on GPU `device`.  Every entry point makes that device the
+ * calling thread's current HIP device and leaves it current.  A context is not
+ * re-entrant: one call at a time per context. */
 int tfhe_hip_create(tfhe_hip_ctx** out, int device);
 void tfhe_hip_destroy(tfhe_hip_ctx* ctx);
 const char* tfhe_hip_last_error(tfhe_hip_ctx* ctx);

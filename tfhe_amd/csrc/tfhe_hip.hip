@@ -1197,6 +1197,11 @@ void tfhe_hip_destroy(tfhe_hip_ctx* ctx) {
   if (ctx->ksblob) (void)hipFree(ctx->ksblob);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->work) (void)hipFree(ctx->work);
+  for (auto& v : ctx->ev)
+    for (auto& pr : v) {
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
   delete ctx;
 }
 
