@@ -975,24 +975,21 @@ bool gate_weights(int gate, Weights* w) {
   }
 }
 
-// scratch layout for a batch of B: bara [B][n], barb [B],
-// ea [B][N], eb [B], ea2 [B][N], eb2 [B]
+// scratch layout for a batch of B: bara [B][n], barb [B], extracted samples ea [B][N], eb [B]
+// (mux asks for 2 B: its two bootstraps run as one batch)
 struct Scratch {
-  int32_t *bara, *barb, *ea, *eb, *ea2, *eb2;
+  int32_t *bara, *barb, *ea, *eb;
 };
 
-int get_scratch(tfhe_hip_ctx* ctx, size_t B, bool two, Scratch* s) {
+int get_scratch(tfhe_hip_ctx* ctx, size_t B, Scratch* s) {
   const size_t n = ctx->P.n;
   auto up = [](size_t x) { return (x + 63) / 64 * 64; };
-  size_t o_bara = 0, o_barb = o_bara + up(B * n * 4);
-  size_t o_ea = o_barb + up(B * 4);
-  size_t o_eb = o_ea + up(B * kN * 4), o_ea2 = o_eb + up(B * 4);
-  size_t o_eb2 = o_ea2 + (two ? up(B * kN * 4) : 0), total = o_eb2 + (two ? up(B * 4) : 0);
+  const size_t o_bara = 0, o_barb = o_bara + up(B * n * 4);
+  const size_t o_ea = o_barb + up(B * 4), o_eb = o_ea + up(B * kN * 4), total = o_eb + up(B * 4);
   if (int rc = ensure_scratch(ctx, total)) return rc;
   char* base = (char*)ctx->scratch;
   s->bara = (int32_t*)(base + o_bara); s->barb = (int32_t*)(base + o_barb);
   s->ea = (int32_t*)(base + o_ea); s->eb = (int32_t*)(base + o_eb);
-  s->ea2 = two ? (int32_t*)(base + o_ea2) : nullptr; s->eb2 = two ? (int32_t*)(base + o_eb2) : nullptr;
   return 0;
 }
 
@@ -1109,7 +1106,7 @@ int run_gate_group(tfhe_hip_ctx* ctx, const GateItem* items, int count) {
   }
   if (total == 0) return 0;
   Scratch s;
-  if (int rc = get_scratch(ctx, total, false, &s)) return rc;
+  if (int rc = get_scratch(ctx, total, &s)) return rc;
   const size_t n = ctx->P.n;
   size_t off = 0;
   for (int k = 0; k < count; k++) {
@@ -1329,7 +1326,7 @@ int tfhe_hip_bootstrap_noks_dev(tfhe_hip_ctx* ctx, int32_t mu, const int32_t* a,
   if (B == 0) return 0;
   if (!a || !b || !out_a || !out_b) return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
   Scratch s;
-  if (int rc = get_scratch(ctx, B, false, &s)) return rc;
+  if (int rc = get_scratch(ctx, B, &s)) return rc;
   if (int rc = launch_prologue(ctx, a, b, nullptr, nullptr, 1, 0, 0, B, s.bara, s.barb)) return rc;
   return launch_blind_rotate(ctx, s.bara, s.barb, mu, nullptr, out_a, out_b, B);
 }
@@ -1348,7 +1345,7 @@ int tfhe_hip_bootstrap_dev(tfhe_hip_ctx* ctx, int32_t mu, const int32_t* a, cons
   if (B == 0) return 0;
   if (!a || !b || !out_a || !out_b) return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
   Scratch s;
-  if (int rc = get_scratch(ctx, B, false, &s)) return rc;
+  if (int rc = get_scratch(ctx, B, &s)) return rc;
   if (int rc = launch_prologue(ctx, a, b, nullptr, nullptr, 1, 0, 0, B, s.bara, s.barb)) return rc;
   if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, mu, nullptr, s.ea, s.eb, B)) return rc;
   return launch_keyswitch(ctx, s.ea, s.eb, nullptr, nullptr, 0, out_a, out_b, var_out, B);
@@ -1364,19 +1361,21 @@ int tfhe_hip_gate_dev(tfhe_hip_ctx* ctx, int gate, const int32_t* ca_a, const in
   Scratch s;
   if (gate == TFHE_HIP_MUX) {                                 // src/gates.rs:239-268
     if (!cc_a || !cc_b) return fail(ctx, TFHE_HIP_ERR_ARG, "mux needs a third operand");
-    if (int rc = get_scratch(ctx, B, true, &s)) return rc;
+    // u1 = bootstrap_noks(and(a, b)), u2 = bootstrap_noks(andny(a, c)) share mu and run as ONE
+    // blind rotation over 2 B ciphertexts; the key switch then takes trivial(1/8) + u1 + u2.
+    if (int rc = get_scratch(ctx, 2 * B, &s)) return rc;
     Weights w1, w2;
     gate_weights(TFHE_HIP_AND, &w1);
     gate_weights(TFHE_HIP_ANDNY, &w2);
+    const size_t n = ctx->P.n;
     if (int rc = launch_prologue(ctx, ca_a, ca_b, cb_a, cb_b, w1.wa, w1.wb, w1.c, B, s.bara, s.barb)) return rc;
-    if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w1.mu, nullptr, s.ea, s.eb, B)) return rc;
-    if (int rc = launch_prologue(ctx, ca_a, ca_b, cc_a, cc_b, w2.wa, w2.wb, w2.c, B, s.bara, s.barb)) return rc;
-    if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w2.mu, nullptr, s.ea2, s.eb2, B)) return rc;
-    return launch_keyswitch(ctx, s.ea, s.eb, s.ea2, s.eb2, 1 << 29, out_a, out_b, var_out, B);
+    if (int rc = launch_prologue(ctx, ca_a, ca_b, cc_a, cc_b, w2.wa, w2.wb, w2.c, B, s.bara + B * n, s.barb + B)) return rc;
+    if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w1.mu, nullptr, s.ea, s.eb, 2 * B)) return rc;
+    return launch_keyswitch(ctx, s.ea, s.eb, s.ea + B * kN, s.eb + B, 1 << 29, out_a, out_b, var_out, B);
   }
   Weights w;
   if (!gate_weights(gate, &w)) return fail(ctx, TFHE_HIP_ERR_ARG, "unknown gate id");
-  if (int rc = get_scratch(ctx, B, false, &s)) return rc;
+  if (int rc = get_scratch(ctx, B, &s)) return rc;
   if (int rc = launch_prologue(ctx, ca_a, ca_b, cb_a, cb_b, w.wa, w.wb, w.c, B, s.bara, s.barb)) return rc;
   if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w.mu, nullptr, s.ea, s.eb, B)) return rc;
   return launch_keyswitch(ctx, s.ea, s.eb, nullptr, nullptr, 0, out_a, out_b, var_out, B);
