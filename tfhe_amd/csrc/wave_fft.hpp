@@ -49,6 +49,13 @@
 #ifndef WFFT_TAIL_CHUNK
 #define WFFT_TAIL_CHUNK 0
 #endif
+// Butterflies that multiply as interleaved inline-asm pairs (1) or plain C++ (0).
+#ifndef WFFT_ASM_DIF
+#define WFFT_ASM_DIF 0
+#endif
+#ifndef WFFT_ASM_DIT
+#define WFFT_ASM_DIT 1
+#endif
 #ifndef WFFT_TWIST_BRANCHFREE
 #define WFFT_TWIST_BRANCHFREE 0
 #endif
@@ -234,18 +241,80 @@ __device__ __forceinline__ void cmul2(double& ar, double& ai, const cplx& wa, do
         : "v"(wa.x), "v"(wa.y), "v"(wb.x), "v"(wb.y));
 }
 
+// Butterflies of one radix-2 stage: b = 0..15, j = b % HALF, operands
+// i0 = (b / HALF) * 2 HALF + j and i1 = i0 + HALF, twiddle w32^(+-TJ) with
+// TJ = j * (16 / HALF).  TJ = 0 and TJ = 8 (w = 1, -+i) need no multiplication.
+template <int HALF>
+__host__ __device__ constexpr int stage_tj(int b) { return (b % HALF) * (16 / HALF); }
+template <int HALF>
+__host__ __device__ constexpr int stage_i0(int b) { return (b / HALF) * 2 * HALF + b % HALF; }
+template <int HALF>
+__host__ __device__ constexpr int nontrivial_count() {
+  int c = 0;
+  for (int b = 0; b < 16; b++) c += (stage_tj<HALF>(b) != 0 && stage_tj<HALF>(b) != 8);
+  return c;
+}
+template <int HALF>
+__host__ __device__ constexpr int nontrivial_butterfly(int k) {      // k-th butterfly that multiplies
+  int c = 0;
+  for (int b = 0; b < 16; b++)
+    if (stage_tj<HALF>(b) != 0 && stage_tj<HALF>(b) != 8) {
+      if (c == k) return b;
+      c++;
+    }
+  return -1;
+}
+
+// Two decimation-in-frequency twiddle products d <- d * w (w = c + i s, constants
+// in scalar registers), multiplications ahead of the FMAs that consume them.
+__device__ __forceinline__ void cmul2_const(double& ar, double& ai, double c0, double s0, double& br,
+                                            double& bi, double c1, double s1) {
+  double t0, t1, t2, t3;
+  asm("v_mul_f64 %4, %1, %9\n\tv_mul_f64 %5, %0, %9\n\tv_mul_f64 %6, %3, %11\n\tv_mul_f64 %7, %2, %11\n\t"
+      "v_fma_f64 %0, %0, %8, -%4\n\tv_fma_f64 %1, %1, %8, %5\n\t"
+      "v_fma_f64 %2, %2, %10, -%6\n\tv_fma_f64 %3, %3, %10, %7"
+      : "+v"(ar), "+v"(ai), "+v"(br), "+v"(bi), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "s"(c0), "s"(s0), "s"(c1), "s"(s1));
+}
+
+// Two decimation-in-time butterflies a' = a + w b, b' = a - w b = 2 a - a' in six
+// FMAs each (instead of a complex product and four additions), interleaved so
+// that every instruction's producer is four instructions back.  The new a comes
+// back in fresh registers (na), b is updated in place.
+__device__ __forceinline__ void dit_butterfly2(double a0r, double a0i, double& b0r, double& b0i, double c0,
+                                               double s0, double& n0r, double& n0i, double a1r, double a1i,
+                                               double& b1r, double& b1i, double c1, double s1, double& n1r,
+                                               double& n1i) {
+  asm("v_fma_f64 %0, -%5, %13, %8\n\tv_fma_f64 %1, %5, %12, %9\n\t"
+      "v_fma_f64 %2, -%7, %15, %10\n\tv_fma_f64 %3, %7, %14, %11\n\t"
+      "v_fma_f64 %0, %4, %12, %0\n\tv_fma_f64 %1, %4, %13, %1\n\t"
+      "v_fma_f64 %2, %6, %14, %2\n\tv_fma_f64 %3, %6, %15, %3\n\t"
+      "v_fma_f64 %4, 2.0, %8, -%0\n\tv_fma_f64 %5, 2.0, %9, -%1\n\t"
+      "v_fma_f64 %6, 2.0, %10, -%2\n\tv_fma_f64 %7, 2.0, %11, -%3"
+      : "=&v"(n0r), "=&v"(n0i), "=&v"(n1r), "=&v"(n1i), "+v"(b0r), "+v"(b0i), "+v"(b1r), "+v"(b1i)
+      : "v"(a0r), "v"(a0i), "v"(a1r), "v"(a1i), "s"(c0), "s"(s0), "s"(c1), "s"(s1));
+}
+
 // Decimation in frequency, natural in -> bit-reversed out.
 template <int HALF, bool INV>
 __device__ __forceinline__ void dif_stage(double (&re)[32], double (&im)[32]) {
   static_for<0, 16>([&](auto ic) WFFT_INLINE {
     constexpr int b = decltype(ic)::value;
-    constexpr int j = b % HALF;
-    constexpr int i0 = (b / HALF) * 2 * HALF + j;
-    constexpr int i1 = i0 + HALF;
+    constexpr int TJ = stage_tj<HALF>(b);
+    constexpr int i0 = stage_i0<HALF>(b), i1 = i0 + HALF;
     const double ar = re[i0], ai = im[i0], br_ = re[i1], bi = im[i1];
     re[i0] = ar + br_;
     im[i0] = ai + bi;
-    mul_w32<j * (16 / HALF), INV>(ar - br_, ai - bi, re[i1], im[i1]);
+    if constexpr (TJ == 0 || TJ == 8 || !WFFT_ASM_DIF) mul_w32<TJ, INV>(ar - br_, ai - bi, re[i1], im[i1]);
+    else { re[i1] = ar - br_; im[i1] = ai - bi; }
+  });
+  static_for<0, WFFT_ASM_DIF ? nontrivial_count<HALF>() / 2 : 0>([&](auto kc) WFFT_INLINE {
+    constexpr int b0 = nontrivial_butterfly<HALF>(2 * decltype(kc)::value);
+    constexpr int b1 = nontrivial_butterfly<HALF>(2 * decltype(kc)::value + 1);
+    constexpr int x0 = stage_i0<HALF>(b0) + HALF, x1 = stage_i0<HALF>(b1) + HALF;
+    constexpr int T0 = stage_tj<HALF>(b0), T1 = stage_tj<HALF>(b1);
+    cmul2_const(re[x0], im[x0], cos32(T0), INV ? sin32(T0) : -sin32(T0), re[x1], im[x1], cos32(T1),
+                INV ? sin32(T1) : -sin32(T1));
   });
 }
 
@@ -254,16 +323,27 @@ template <int HALF, bool INV>
 __device__ __forceinline__ void dit_stage(double (&re)[32], double (&im)[32]) {
   static_for<0, 16>([&](auto ic) WFFT_INLINE {
     constexpr int b = decltype(ic)::value;
-    constexpr int j = b % HALF;
-    constexpr int i0 = (b / HALF) * 2 * HALF + j;
-    constexpr int i1 = i0 + HALF;
-    double tr, ti;
-    mul_w32<j * (16 / HALF), INV>(re[i1], im[i1], tr, ti);
-    const double ar = re[i0], ai = im[i0];
-    re[i0] = ar + tr;
-    im[i0] = ai + ti;
-    re[i1] = ar - tr;
-    im[i1] = ai - ti;
+    constexpr int TJ = stage_tj<HALF>(b);
+    if constexpr (TJ == 0 || TJ == 8 || !WFFT_ASM_DIT) {
+      constexpr int i0 = stage_i0<HALF>(b), i1 = i0 + HALF;
+      double tr, ti;
+      mul_w32<TJ, INV>(re[i1], im[i1], tr, ti);
+      const double ar = re[i0], ai = im[i0];
+      re[i0] = ar + tr;
+      im[i0] = ai + ti;
+      re[i1] = ar - tr;
+      im[i1] = ai - ti;
+    }
+  });
+  static_for<0, WFFT_ASM_DIT ? nontrivial_count<HALF>() / 2 : 0>([&](auto kc) WFFT_INLINE {
+    constexpr int b0 = nontrivial_butterfly<HALF>(2 * decltype(kc)::value);
+    constexpr int b1 = nontrivial_butterfly<HALF>(2 * decltype(kc)::value + 1);
+    constexpr int x0 = stage_i0<HALF>(b0), y0 = x0 + HALF, x1 = stage_i0<HALF>(b1), y1 = x1 + HALF;
+    constexpr int T0 = stage_tj<HALF>(b0), T1 = stage_tj<HALF>(b1);
+    double n0r, n0i, n1r, n1i;
+    dit_butterfly2(re[x0], im[x0], re[y0], im[y0], cos32(T0), INV ? sin32(T0) : -sin32(T0), n0r, n0i,
+                   re[x1], im[x1], re[y1], im[y1], cos32(T1), INV ? sin32(T1) : -sin32(T1), n1r, n1i);
+    re[x0] = n0r; im[x0] = n0i; re[x1] = n1r; im[x1] = n1i;
   });
 }
 
