@@ -287,6 +287,36 @@ def test_blind_rotate_mappings_agree_at_full_size(level):
         assert (out["batch"][0][i] == wa).all() and out["batch"][1][i] == wb and out["batch"][2][i] == wv
 
 
+def test_full_batch_properties():
+    """The bench's batch size (16 384 gates, Bit80): properties that need no oracle.
+    Symmetric gates do not care about operand order (their prologue is a wrapping sum),
+    repeating a ciphertext inside the batch repeats its result, and a second run of the
+    same batch returns the same bits; one ciphertext is checked against the oracle."""
+    import tfhe_amd
+    P = orc.params(80)
+    K = orc.generate_synthetic_keys(P, 170)
+    B = 16384
+    ca = (orc.uniform_i32(171, (B, P.n)), orc.uniform_i32(172, (B,)))
+    cb = (orc.uniform_i32(173, (B, P.n)), orc.uniform_i32(174, (B,)))
+    for arr_a, arr_b in ((ca[0], cb[0]), (ca[1], cb[1])):      # ciphertext B-1 repeats ciphertext 5
+        arr_a[B - 1] = arr_a[5]
+        arr_b[B - 1] = arr_b[5]
+    e = tfhe_amd.Engine(0)
+    try:
+        _load(e, P, K)
+        r1 = e.gate("nand", ca, cb, want_var=True)
+        r2 = e.gate("nand", cb, ca, want_var=True)
+        r3 = e.gate("nand", ca, cb, want_var=True)
+    finally:
+        e.close()
+    for x, y, z in zip(r1, r2, r3):
+        assert (x == y).all() and (x == z).all()
+    assert (r1[0][B - 1] == r1[0][5]).all() and r1[1][B - 1] == r1[1][5] and r1[2][B - 1] == r1[2][5]
+    i = B // 2 + 1
+    wa, wb, wv = orc.gate(P, "nand", K, (ca[0][i], ca[1][i], 0.0), (cb[0][i], cb[1][i], 0.0), None, orc.MUL_EXACT)
+    assert (r1[0][i] == wa).all() and r1[1][i] == wb and r1[2][i] == wv
+
+
 def test_errors_are_reported_not_thrown(eng):
     import ctypes as C
     import tfhe_amd
