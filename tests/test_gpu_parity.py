@@ -156,6 +156,41 @@ def test_keyswitch(eng, n, n_ks):
         assert var[i] == wv, i
 
 
+@pytest.mark.parametrize("n", [20, 630])
+def test_keyswitch_large_batch(n):
+    """Batches of at least 8 ciphertexts per compute unit take the tiled key switch (one
+    pass over the key for 8 ciphertexts); a ragged batch must equal the per-ciphertext
+    kernel (same inputs in small chunks) and the oracle."""
+    import tfhe_amd
+    P = orc.small_params(n=n)
+    P.l, P.bg_bit = 2, 10
+    K = orc.generate_synthetic_keys(P, 140 + n)
+    B = 2051
+    a = orc.uniform_i32(141, (B, 1024))
+    b = orc.uniform_i32(142, (B,))
+    a[7, :] = 0
+    e = tfhe_amd.Engine(0)
+    try:
+        e.load_keys(_hip_params(P), K["bk"], K["ks_a"], K["ks_b"], K["ks_var"])
+        oa, ob, var = e.keyswitch(a, b, want_var=True)
+        for lo in range(0, B, 700):
+            ca, cb, cv = e.keyswitch(a[lo:lo + 700], b[lo:lo + 700], want_var=True)
+            assert (oa[lo:lo + 700] == ca).all() and (ob[lo:lo + 700] == cb).all() and (var[lo:lo + 700] == cv).all()
+        # mux form (two inputs and the constant) on the tiled path
+        ca = (orc.uniform_i32(143, (B, P.n)), orc.uniform_i32(144, (B,)))
+        cb = (orc.uniform_i32(145, (B, P.n)), orc.uniform_i32(146, (B,)))
+        cc = (orc.uniform_i32(147, (B, P.n)), orc.uniform_i32(148, (B,)))
+        ma, mb, mv = e.gate("mux", ca, cb, cc, want_var=True)
+    finally:
+        e.close()
+    for i in (0, 7, B - 1):
+        wa, wb, wv = orc.key_switch(P, K["ks_a"], K["ks_b"], a[i], b[i], K["ks_var"])
+        assert (oa[i] == wa).all() and ob[i] == wb and var[i] == wv, i
+        wa, wb, wv = orc.gate(P, "mux", K, (ca[0][i], ca[1][i], 0.0), (cb[0][i], cb[1][i], 0.0),
+                              (cc[0][i], cc[1][i], 0.0), orc.MUL_EXACT)
+        assert (ma[i] == wa).all() and mb[i] == wb and mv[i] == wv, i
+
+
 @pytest.mark.parametrize("tag", ["l2", "l3"])
 def test_gates_small_n(eng, tag):
     l, bg = SHAPES[tag]

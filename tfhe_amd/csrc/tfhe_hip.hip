@@ -828,6 +828,108 @@ __global__ __launch_bounds__(kKsBlock) void keyswitch_kernel(
   }
 }
 
+// lwe_key_switch for large batches: one workgroup takes kKsTile ciphertexts and
+// walks the key once for all of them, so a key row is fetched once per tile
+// instead of once per ciphertext (the gather is bound by L2 / Infinity Cache
+// bandwidth, not by arithmetic).  For every (coefficient, digit position) the
+// three rows of the non-zero digits are loaded and each ciphertext subtracts the
+// one its digit selects; the digit is wave-uniform, so the selection is a scalar
+// branch.  Thread layout and the order of the variance sum as in keyswitch_kernel.
+constexpr int kKsTile = 8;
+
+template <int T>
+__global__ __launch_bounds__(kKsBlock) void keyswitch_tile_kernel(
+    const int32_t* __restrict__ in_a, const int32_t* __restrict__ in_b,
+    const int32_t* __restrict__ in2_a, const int32_t* __restrict__ in2_b, int32_t c_b,
+    int in_stride, const int32_t* __restrict__ ks_rows, const double* __restrict__ ks_var,
+    int row_stride, int n, int n_ks, int B, int32_t* __restrict__ out_a,
+    int32_t* __restrict__ out_b, double* __restrict__ var_out) {
+  __shared__ int32_t aibar_s[kKsTile][kN];
+  __shared__ int4 part[kKsBlock];
+  const int b0 = blockIdx.x * kKsTile;
+  const int nvec = row_stride / 4;
+  const int tpg = (nvec + 63) / 64 * 64;      // whole wavefronts per group: the digits stay wave-uniform
+  const int G = kKsBlock / tpg;
+  const int g = threadIdx.x / tpg, v = threadIdx.x - g * tpg;
+  const int32_t prec_offset = 1 << (32 - (1 + 2 * T));
+  for (int c = 0; c < kKsTile; c++) {
+    const int b = b0 + c;
+    for (int i = threadIdx.x; i < n_ks; i += kKsBlock) {
+      int32_t x = 0;                                  // all digits 0: nothing is subtracted
+      if (b < B) {
+        int32_t ai = in_a[(size_t)b * in_stride + i];
+        if (in2_a) ai = wadd(ai, in2_a[(size_t)b * in_stride + i]);
+        x = wadd(ai, prec_offset);
+      }
+      aibar_s[c][i] = x;
+    }
+  }
+  __syncthreads();
+  uint32_t acc[kKsTile][4];
+#pragma unroll
+  for (int c = 0; c < kKsTile; c++) acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0;
+  if (g < G && v < nvec) {
+    const int32_t* col = ks_rows + 4 * v;
+    for (int i = g; i < n_ks; i += G) {
+      int32_t ab[kKsTile];
+#pragma unroll
+      for (int c = 0; c < kKsTile; c++) ab[c] = __builtin_amdgcn_readfirstlane(aibar_s[c][i]);
+#pragma unroll 2
+      for (int j = 0; j < T; j++) {
+        const int32_t* r = col + (size_t)(i * T + j) * 4 * row_stride;
+        const int4 r1 = *reinterpret_cast<const int4*>(r + row_stride);
+        const int4 r2 = *reinterpret_cast<const int4*>(r + 2 * row_stride);
+        const int4 r3 = *reinterpret_cast<const int4*>(r + 3 * row_stride);
+        const int sh = 32 - (j + 1) * 2;
+#pragma unroll
+        for (int c = 0; c < kKsTile; c++) {
+          const int d = (ab[c] >> sh) & 3;            // uniform
+          if (d != 0) {
+            const int4 row = d == 1 ? r1 : (d == 2 ? r2 : r3);
+            acc[c][0] -= (uint32_t)row.x; acc[c][1] -= (uint32_t)row.y;
+            acc[c][2] -= (uint32_t)row.z; acc[c][3] -= (uint32_t)row.w;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < kKsTile; c++) {
+    const int b = b0 + c;
+    __syncthreads();
+    part[threadIdx.x] = make_int4((int)acc[c][0], (int)acc[c][1], (int)acc[c][2], (int)acc[c][3]);
+    __syncthreads();
+    if (b < B && g == 0 && v < nvec) {
+      uint32_t a4[4] = {acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
+      for (int k = 1; k < G; k++) {
+        const int4 o = part[k * tpg + v];
+        a4[0] += (uint32_t)o.x; a4[1] += (uint32_t)o.y; a4[2] += (uint32_t)o.z; a4[3] += (uint32_t)o.w;
+      }
+      for (int e = 0; e < 4; e++) {
+        const int x = 4 * v + e;
+        if (x < n) out_a[(size_t)b * n + x] = (int32_t)a4[e];
+        else if (x == n) {
+          int32_t bb = in_b[b];
+          if (in2_b) bb = wadd(wadd(c_b, bb), in2_b[b]);
+          out_b[b] = wadd(bb, (int32_t)a4[e]);
+        }
+      }
+    }
+  }
+  // variances: thread kKsBlock-1-c sums ciphertext c in the reference's order (lwe.rs:109)
+  const int cv = kKsBlock - 1 - (int)threadIdx.x;
+  if (var_out && cv >= 0 && cv < kKsTile && b0 + cv < B) {
+    double var = 0.0;
+    for (int i = 0; i < n_ks; i++) {
+      const int32_t aibar = aibar_s[cv][i];
+      const double* vi = ks_var + (size_t)i * T * 4;
+#pragma unroll
+      for (int j = 0; j < T; j++) var += vi[j * 4 + ((aibar >> (32 - (j + 1) * 2)) & 3)];
+    }
+    var_out[b0 + cv] = var;
+  }
+}
+
 __global__ void fill_kernel(int32_t* __restrict__ p, int32_t v, size_t count) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) p[i] = v;
@@ -1047,7 +1149,13 @@ int launch_keyswitch(tfhe_hip_ctx* ctx, const int32_t* in_a, const int32_t* in_b
                      double* var_out, size_t B) {
   const double* ks_var = (const double*)(ctx->ksblob + ctx->ks_rows_bytes);
   ProfileScope prof(ctx, 2);
-  if (ctx->P.ks_t == 8)
+  if (ctx->P.ks_t == 8 && B >= (size_t)ctx->num_cus * kKsTile) {
+    // enough ciphertexts to give every compute unit a tile: share the key reads
+    const unsigned grid = (unsigned)((B + kKsTile - 1) / kKsTile);
+    hipLaunchKernelGGL(keyswitch_tile_kernel<8>, dim3(grid), dim3(kKsBlock), 0, ctx->stream, in_a, in_b, in2_a,
+                       in2_b, c_b, kN, (const int32_t*)ctx->ksblob, ks_var, ctx->row_stride, ctx->P.n,
+                       ctx->P.n_ks, (int)B, out_a, out_b, var_out);
+  } else if (ctx->P.ks_t == 8)
     hipLaunchKernelGGL(keyswitch_kernel<8>, dim3((unsigned)B), dim3(kKsBlock), 0, ctx->stream, in_a, in_b,
                        in2_a, in2_b, c_b, kN, (const int32_t*)ctx->ksblob, ks_var, ctx->row_stride,
                        ctx->P.n, ctx->P.n_ks, ctx->P.ks_t, out_a, out_b, var_out);
