@@ -20,7 +20,7 @@ for kind in ("fetch", "write", "sq"):
     agg = collections.defaultdict(float); cnt = collections.Counter()
     for row in csv.DictReader(open(f)):
         kn = row["Kernel_Name"]
-        k = ("blind_rotate_kernel<2,10,false>" if "blind_rotate" in kn else "keyswitch_kernel<8>" if "keyswitch" in kn
+        k = ("blind_rotate_kernel<2,10,false>" if "blind_rotate" in kn else "keyswitch_tile_kernel<8>" if "keyswitch" in kn
              else "prologue_kernel" if "prologue" in kn else None)
         if k is None: continue
         agg[(k, row["Counter_Name"])] += float(row["Counter_Value"]); cnt[(k, row["Counter_Name"])] += 1
