@@ -1,5 +1,9 @@
-"""Copies the summaries of a gpurun_out/<dir> produced by the measurement command line of DESIGN.md
-section 6 into profiles/ (kernel stats, bench lines, PMC sums per kernel, traffic)."""
+"""Copies the summaries of one measurement pass into profiles/ (kernel stats, bench lines, PMC sums
+per kernel, traffic).  The pass directory holds bench80.json, bench128.json, bench80_refkeys.json,
+add32.json, polymul.json (bench.py lines), prof/ (rocprofv3 --kernel-trace --stats --output-format csv),
+pmc_fetch/, pmc_write/, pmc_sq/ (rocprofv3 --pmc ... --kernel-trace --output-format csv of
+`bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-latency`) and bench_prof.log.
+usage: python tools/collect_profiles.py gpurun_out/<pass>"""
 import collections, csv, glob, json, shutil, sys
 R, P = sys.argv[1], "profiles"
 names = {"bench80": "r01_bench_bit80", "bench128": "r01_bench_bit128", "bench80_refkeys": "r01_bench_bit80_reference_style_keys",
