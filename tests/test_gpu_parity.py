@@ -322,6 +322,29 @@ def test_blind_rotate_mappings_agree_at_full_size(level):
         assert (out["batch"][0][i] == wa).all() and out["batch"][1][i] == wb and out["batch"][2][i] == wv
 
 
+def test_random_small_configurations(eng):
+    """Seeded sweep over ragged shapes: n from 1, batches from 1 (including sizes that leave
+    wavefront slots of the last workgroup empty), both decomposition shapes, every gate kind."""
+    rng = np.random.default_rng(20240607)
+    for trial in range(12):
+        tag = ("l2", "l3")[trial % 2]
+        l, bg = SHAPES[tag]
+        n = int(rng.integers(1, 14))
+        B = int(rng.integers(1, 11))
+        P = orc.small_params(n=n, l=l, bg_bit=bg)
+        K = orc.generate_synthetic_keys(P, 300 + trial)
+        _load(eng, P, K)
+        ca = (orc.uniform_i32(400 + trial, (B, n)), orc.uniform_i32(500 + trial, (B,)))
+        cb = (orc.uniform_i32(600 + trial, (B, n)), orc.uniform_i32(700 + trial, (B,)))
+        cc = (orc.uniform_i32(800 + trial, (B, n)), orc.uniform_i32(900 + trial, (B,)))
+        g = orc.GATES[trial % 11]
+        oa, ob, var = eng.gate(g, ca, cb, cc if g == "mux" else None, want_var=True)
+        for i in range(B):
+            wa, wb, wv = orc.gate(P, g, K, (ca[0][i], ca[1][i], 0.0), (cb[0][i], cb[1][i], 0.0),
+                                  (cc[0][i], cc[1][i], 0.0), orc.MUL_EXACT)
+            assert (oa[i] == wa).all() and ob[i] == wb and var[i] == wv, (trial, tag, n, B, g, i)
+
+
 def test_full_batch_properties():
     """The bench's batch size (16 384 gates, Bit80): properties that need no oracle.
     Symmetric gates do not care about operand order (their prologue is a wrapping sum),
