@@ -17,7 +17,11 @@
  *    and return when the result is in the caller's buffers.  The `_dev`
  *    variants take DEVICE pointers on the context's GPU, enqueue on the
  *    context's stream and return without synchronising.
- *  - A context is bound to one GPU and is not re-entrant: one call at a time.
+ *  - A context is bound to one GPU (tfhe_hip_create) or to a list of GPUs
+ *    (tfhe_hip_create_multi) and is not re-entrant: one call at a time.
+ *  - Host-pointer entry points stage through buffers the context keeps (a device
+ *    buffer and a pinned host buffer, grown on demand, freed by tfhe_hip_destroy):
+ *    after the first call of a given size they allocate nothing.
  *  - There is no CPU fallback: without a usable GPU tfhe_hip_create fails.
  */
 #ifndef TFHE_HIP_H
@@ -58,10 +62,31 @@ enum {
  * calling thread's current HIP device and leaves it current.  A context is not
  * re-entrant: one call at a time per context. */
 int tfhe_hip_create(tfhe_hip_ctx** out, int device);
+/* A context over `ndev` GPUs (devices[i] may repeat: each entry is one worker
+ * with a stream of its own).  The reference's callers are one single-threaded
+ * process (src/gates.rs:35, src/bootstrapping.rs:25-29, benches/bootstrapping.rs:21);
+ * through this context that one process drives every listed GPU:
+ *   - tfhe_hip_load_keys / tfhe_hip_load_keys_blob transform the keys on
+ *     devices[0] and replicate the device blobs once: an RCCL broadcast
+ *     (ncclCommInitAll + ncclBroadcast over xGMI) between distinct GPUs,
+ *     peer-to-peer copies if RCCL is unavailable, a device-to-device copy
+ *     between workers that share a GPU;
+ *   - every host-pointer entry point and every tfhe_hip_samples_* call splits its
+ *     batch contiguously over the workers (tfhe_hip_circuit_add by instance, so
+ *     that all dependency levels of an instance stay on one GPU), runs the
+ *     shards at the same time and joins them; there is no data-path collective;
+ *   - the parity hooks (tfhe_hip_extprod*, tfhe_hip_blind_rotate,
+ *     tfhe_hip_polymul_margin) run on devices[0];
+ *   - the `_dev` entry points, tfhe_hip_set_stream and the key export/import
+ *     need a single-device context and fail with TFHE_HIP_ERR_ARG here.
+ * Results are bit-identical to those of a single-device context. */
+int tfhe_hip_create_multi(tfhe_hip_ctx** out, const int* devices, int ndev);
 void tfhe_hip_destroy(tfhe_hip_ctx* ctx);
 const char* tfhe_hip_last_error(tfhe_hip_ctx* ctx);
 
-/* Work is enqueued on `hip_stream` (a hipStream_t; NULL = the default stream). */
+/* Work is enqueued on `hip_stream` (a hipStream_t; NULL = the default stream).
+ * Waits for the work already enqueued on the previous stream first: the
+ * context's scratch buffers are shared by all calls. */
 int tfhe_hip_set_stream(tfhe_hip_ctx* ctx, void* hip_stream);
 /* Waits for the context's stream. */
 int tfhe_hip_synchronize(tfhe_hip_ctx* ctx);
@@ -96,6 +121,28 @@ int tfhe_hip_profile_read(tfhe_hip_ctx* ctx, double ms_sum[3], int launches[3]);
  * Transforms the bootstrapping key to its FFT-domain form on the GPU. */
 int tfhe_hip_load_keys(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, const int32_t* bk,
                        const int32_t* ks_a, const int32_t* ks_b, const double* ks_var);
+
+/* The key file: one flat little-endian image of the key material above, so that
+ * keys are generated once and loaded from disk (the reference derives
+ * Serialize/Deserialize for CloudKey, LweBootstrappingKey and LweKeySwitchKey,
+ * src/lwe.rs:247-251,432-446,495-514, but depends on no serializer, so it
+ * defines no byte format of its own).  Layout:
+ *    0  char[8]  "TFHEHIPK"
+ *    8  u32      version (1)          12  u32  header size (64)
+ *   16  i32[8]   n, N, k, l, bg_bit, ks_t, ks_base_bit, n_ks
+ *   48  u32      1 if the variances are present      52  u32  0
+ *   56  u64      bytes that follow the header
+ *   64  i32      bk [n][l][k+1][k+1][N], then ks_a [n_ks][t][base][n], then
+ *                ks_b [n_ks][t][base]; zero padding to a multiple of 8; then
+ *                f64 ks_var [n_ks][t][base] if present
+ * i.e. the Vec<i32> payloads of the serde field order without length prefixes.
+ * tfhe_hip_key_file_size: size of the image; tfhe_hip_key_file_pack: writes it
+ * into `out` (capacity bytes; ks_var may be NULL); tfhe_hip_load_keys_blob:
+ * validates an image and loads it as tfhe_hip_load_keys does. */
+int tfhe_hip_key_file_size(const tfhe_hip_params* params, int has_ks_var, size_t* bytes);
+int tfhe_hip_key_file_pack(const tfhe_hip_params* params, const int32_t* bk, const int32_t* ks_a,
+                           const int32_t* ks_b, const double* ks_var, void* out, size_t capacity);
+int tfhe_hip_load_keys_blob(tfhe_hip_ctx* ctx, const void* blob, size_t bytes);
 
 /* Sizes in bytes of the two device-side key blobs (FFT-domain bootstrapping
  * key; key-switch rows followed by their variances). */
@@ -139,6 +186,38 @@ int tfhe_hip_gate_dev(tfhe_hip_ctx* ctx, int gate, const int32_t* ca_a, const in
                       const int32_t* cc_b, int32_t* out_a, int32_t* out_b, double* var_out,
                       size_t B);
 
+/* gates::not (src/gates.rs:122-124: mask and body negated, variance kept; `var`
+ * may be NULL = zeros) and gates::constant (src/gates.rs:12-20: the noiseless
+ * trivial sample of +-1/8) on device buffers. */
+int tfhe_hip_not_dev(tfhe_hip_ctx* ctx, const int32_t* a, const int32_t* b, const double* var,
+                     int32_t* out_a, int32_t* out_b, double* var_out, size_t B);
+int tfhe_hip_constant_dev(tfhe_hip_ctx* ctx, int value, int32_t* out_a, int32_t* out_b,
+                          double* var_out, size_t B);
+
+/* Device-resident LweSample batches (src/lwe.rs:20-27: coefficients, b,
+ * current_variance), so that chained gates never return to the host: a handle
+ * owns a [B][n] mask, [B] body and [B] variance array on the context's GPU (on
+ * a multi-GPU context: one contiguous share per worker).  Handles are made for
+ * the loaded keys' n; upload and download copy whole batches and return when the
+ * caller's buffers may be reused / are filled; the gate calls only enqueue.
+ * var may be NULL (upload: zeros; download: skipped). */
+typedef struct tfhe_hip_samples tfhe_hip_samples;
+int tfhe_hip_samples_alloc(tfhe_hip_ctx* ctx, size_t B, tfhe_hip_samples** out);
+void tfhe_hip_samples_free(tfhe_hip_samples* s);
+size_t tfhe_hip_samples_count(const tfhe_hip_samples* s);
+int tfhe_hip_samples_upload(tfhe_hip_ctx* ctx, tfhe_hip_samples* s, const int32_t* a,
+                            const int32_t* b, const double* var);
+int tfhe_hip_samples_download(tfhe_hip_ctx* ctx, const tfhe_hip_samples* s, int32_t* a, int32_t* b,
+                              double* var);
+/* out = gate(ca, cb[, cc]) as tfhe_hip_gate; out may not alias an operand. */
+int tfhe_hip_samples_gate(tfhe_hip_ctx* ctx, int gate, const tfhe_hip_samples* ca,
+                          const tfhe_hip_samples* cb, const tfhe_hip_samples* cc,
+                          tfhe_hip_samples* out);
+int tfhe_hip_samples_bootstrap(tfhe_hip_ctx* ctx, int32_t mu, const tfhe_hip_samples* x,
+                               tfhe_hip_samples* out);
+int tfhe_hip_samples_not(tfhe_hip_ctx* ctx, const tfhe_hip_samples* x, tfhe_hip_samples* out);
+int tfhe_hip_samples_constant(tfhe_hip_ctx* ctx, int value, tfhe_hip_samples* out);
+
 /* circuits::add (src/circuits/circuits.rs:105-120, full_adder :83-97), the
  * ripple-carry adder, on `count` independent pairs of `bits`-bit operands, run
  * level by level so that every launch holds the gates of all instances that are
@@ -168,13 +247,36 @@ int tfhe_hip_polymul(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, int3
 int tfhe_hip_polymul_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, int32_t* out,
                          int accumulate, size_t B);
 
+/* Rounding margin of the products above, measured inside the kernel: the
+ * reference rounds each coefficient of an f64 FFT product to the nearest integer
+ * (src/numerics.rs:253-258), so two FFTs agree on the result as long as each
+ * one's error stays below 0.5.  margin [B][2] receives, per product, the largest
+ * |x - rint(x)| before rounding over all 2N-1 coefficients and the largest over
+ * the coefficients whose rounding decides the result (|rint(x)| <= 2^31; larger
+ * values saturate whatever their fraction is).  Test hook; nothing else is
+ * written. */
+int tfhe_hip_polymul_margin(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, double* margin,
+                            size_t B);
+int tfhe_hip_polymul_margin_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s,
+                                double* margin, size_t B);
+
 /* tgsw_extern_mul_to_tlwe (src/tgsw.rs:229-264) of B accumulators
- * t [B][k+2][N] with the loaded bk[bk_index]; out [B][k+2][N]. */
+ * t [B][k+2][N] with the loaded bk[bk_index]; out [B][k+2][N].  The _margin
+ * form also returns the rounding margins (as above, over the 4 l products of
+ * each accumulator) in margin [B][2], which may be NULL. */
 int tfhe_hip_extprod(tfhe_hip_ctx* ctx, const int32_t* t, int bk_index, int32_t* out, size_t B);
+int tfhe_hip_extprod_margin(tfhe_hip_ctx* ctx, const int32_t* t, int bk_index, int32_t* out,
+                            double* margin, size_t B);
+int tfhe_hip_extprod_dev(tfhe_hip_ctx* ctx, const int32_t* t, int bk_index, int32_t* out,
+                         double* margin, size_t B);
 
 /* tfhe_blind_rotate (src/bootstrapping.rs:109-134) of B accumulators
- * acc [B][k+2][N] (updated in place) by bara [B][n] with the loaded key. */
+ * acc [B][k+2][N] (updated in place) by bara [B][n] with the loaded key.  Every
+ * i32 is accepted as a rotation amount and reduced as mul_by_monomial does
+ * (src/polynomial.rs:289-291: (bara / N) mod 2 picks the sign pattern, bara % N
+ * the shift); the bootstrap itself only produces [-N, N-1]. */
 int tfhe_hip_blind_rotate(tfhe_hip_ctx* ctx, int32_t* acc, const int32_t* bara, size_t B);
+int tfhe_hip_blind_rotate_dev(tfhe_hip_ctx* ctx, int32_t* acc, const int32_t* bara, size_t B);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,15 @@ SYMBOLS = [
     "tfhe_hip_keyswitch", "tfhe_hip_keyswitch_dev", "tfhe_hip_gate", "tfhe_hip_gate_dev",
     "tfhe_hip_polymul", "tfhe_hip_polymul_dev", "tfhe_hip_extprod", "tfhe_hip_blind_rotate",
     "tfhe_hip_profile_enable", "tfhe_hip_profile_read",
+    "tfhe_hip_create_multi", "tfhe_hip_key_file_size", "tfhe_hip_key_file_pack", "tfhe_hip_load_keys_blob",
+    "tfhe_hip_not_dev", "tfhe_hip_constant_dev",
+    "tfhe_hip_samples_alloc", "tfhe_hip_samples_free", "tfhe_hip_samples_count", "tfhe_hip_samples_upload",
+    "tfhe_hip_samples_download", "tfhe_hip_samples_gate", "tfhe_hip_samples_bootstrap",
+    "tfhe_hip_samples_not", "tfhe_hip_samples_constant",
+    "tfhe_hip_polymul_margin", "tfhe_hip_polymul_margin_dev", "tfhe_hip_extprod_margin",
+    "tfhe_hip_extprod_dev", "tfhe_hip_blind_rotate_dev",
 ]
+NO_INT_RESULT = ("tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_samples_free", "tfhe_hip_samples_count")
 
 
 class Params(C.Structure):
@@ -69,9 +77,31 @@ def load():
     lib.tfhe_hip_profile_enable.argtypes = [vp, C.c_int]
     lib.tfhe_hip_profile_read.argtypes = [vp, C.POINTER(C.c_double * 3), C.POINTER(C.c_int * 3)]
     lib.tfhe_hip_extprod.argtypes = [vp, i32p, C.c_int, i32p, sz]
-    lib.tfhe_hip_blind_rotate.argtypes = [vp, i32p, i32p, sz]
+    lib.tfhe_hip_extprod_margin.argtypes = [vp, i32p, C.c_int, i32p, f64p, sz]
+    lib.tfhe_hip_extprod_dev.argtypes = [vp, i32p, C.c_int, i32p, f64p, sz]
+    for name in ("tfhe_hip_blind_rotate", "tfhe_hip_blind_rotate_dev"):
+        getattr(lib, name).argtypes = [vp, i32p, i32p, sz]
+    for name in ("tfhe_hip_polymul_margin", "tfhe_hip_polymul_margin_dev"):
+        getattr(lib, name).argtypes = [vp, i32p, i32p, f64p, sz]
+    lib.tfhe_hip_create_multi.argtypes = [C.POINTER(vp), C.POINTER(C.c_int), C.c_int]
+    lib.tfhe_hip_key_file_size.argtypes = [PP, C.c_int, C.POINTER(sz)]
+    lib.tfhe_hip_key_file_pack.argtypes = [PP, i32p, i32p, i32p, f64p, vp, sz]
+    lib.tfhe_hip_load_keys_blob.argtypes = [vp, vp, sz]
+    lib.tfhe_hip_not_dev.argtypes = [vp, i32p, i32p, f64p, i32p, i32p, f64p, sz]
+    lib.tfhe_hip_constant_dev.argtypes = [vp, C.c_int, i32p, i32p, f64p, sz]
+    lib.tfhe_hip_samples_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.tfhe_hip_samples_free.argtypes = [vp]
+    lib.tfhe_hip_samples_free.restype = None
+    lib.tfhe_hip_samples_count.argtypes = [vp]
+    lib.tfhe_hip_samples_count.restype = sz
+    lib.tfhe_hip_samples_upload.argtypes = [vp, vp, i32p, i32p, f64p]
+    lib.tfhe_hip_samples_download.argtypes = [vp, vp, i32p, i32p, f64p]
+    lib.tfhe_hip_samples_gate.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    lib.tfhe_hip_samples_bootstrap.argtypes = [vp, C.c_int32, vp, vp]
+    lib.tfhe_hip_samples_not.argtypes = [vp, vp, vp]
+    lib.tfhe_hip_samples_constant.argtypes = [vp, C.c_int, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
-        if name not in ("tfhe_hip_destroy", "tfhe_hip_last_error"):
+        if name not in NO_INT_RESULT:
             fn.restype = C.c_int
     return lib

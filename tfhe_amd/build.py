@@ -1,26 +1,49 @@
-"""Builds libtfhe_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Builds libtfhe_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+Two translation units: csrc/tfhe_hip.hip (kernels and the device-pointer entry
+points) and csrc/host_api.cpp (host layer: staging, sample handles, key file,
+multi-GPU contexts).  Each is compiled to an object only when it is stale.
+"""
 import os
 import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "tfhe_hip.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "wave_fft.hpp"),
-        os.path.join(os.path.dirname(HERE), "include", "tfhe_hip.h")]
+CSRC = os.path.join(HERE, "csrc")
+HEADER = os.path.join(os.path.dirname(HERE), "include", "tfhe_hip.h")
+COMMON_DEPS = [os.path.join(CSRC, "ctx.hpp"), HEADER]
+UNITS = [
+    # (source, object, extra dependencies, extra flags)
+    (os.path.join(CSRC, "tfhe_hip.hip"), os.path.join(CSRC, "tfhe_hip.o"),
+     [os.path.join(CSRC, "wave_fft.hpp")],
+     # max-ilp scheduling: one wavefront per SIMD has nobody to hide a dependent
+     # instruction's latency behind, so independent work is interleaved by the compiler
+     ["--offload-arch=gfx950", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+    (os.path.join(CSRC, "host_api.cpp"), os.path.join(CSRC, "host_api.o"), [],
+     ["-x", "hip", "--offload-arch=gfx950", "-Wall", "-Wextra"]),
+]
+SRC = UNITS[0][0]
 OUT = os.path.join(HERE, "libtfhe_hip.so")
 
 
+def _stale(target, deps):
+    return not os.path.exists(target) or os.path.getmtime(target) < max(os.path.getmtime(d) for d in deps)
+
+
 def build_library(force=False, verbose=False):
-    if (not force and os.path.exists(OUT)
-            and os.path.getmtime(OUT) >= max(os.path.getmtime(d) for d in DEPS)):
-        return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # max-ilp scheduling: one wavefront per SIMD has nobody to hide a dependent
-    # instruction's latency behind, so independent work is interleaved by the compiler
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-o", OUT, SRC]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-    subprocess.check_call(cmd)
+    objs = []
+    relink = force or not os.path.exists(OUT)
+    for src, obj, deps, flags in UNITS:
+        if force or _stale(obj, [src] + deps + COMMON_DEPS):
+            cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-c"] + flags + ["-o", obj, src]
+            if verbose and src.endswith(".hip"):
+                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            subprocess.check_call(cmd)
+            relink = True
+        objs.append(obj)
+    if relink or _stale(OUT, objs):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+                              + ["-ldl", "-lpthread"])
     return OUT
 
 

@@ -23,7 +23,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/tfhe_hip.h"
+#include "ctx.hpp"
 #include "wave_fft.hpp"
 
 using wfft::cplx;
@@ -78,6 +78,18 @@ __device__ __forceinline__ int32_t wneg(int32_t a) { return (int32_t)(0u - (uint
 
 // decode_message(x, 2N), src/numerics.rs:126-130 with N = 1024.
 __device__ __forceinline__ int32_t mod_switch_2n(int32_t x) { return wadd(x, 1 << 20) >> 21; }
+
+// The power of mul_by_monomial reduced as src/polynomial.rs:289-291 does it:
+// cycle = (power / N).modulo(2) == 1, pw = power % N (truncating division and
+// remainder; the low bit of a two's-complement quotient is its positive
+// remainder modulo 2).  Any i32 power is accepted.
+struct MonomialPower {
+  int pw;
+  bool cycle;
+};
+__device__ __forceinline__ MonomialPower monomial_power(int power) {
+  return {power % kN, ((power / kN) & 1) != 0};
+}
 
 // Copies the two twiddle tables (tE then twist, 1024 entries each) into LDS.
 __device__ __forceinline__ void load_tables(char* lds_tables, const cplx* __restrict__ tables) {
@@ -223,13 +235,27 @@ __device__ __forceinline__ void level_product(int p, const char* tt, const cplx*
   TFHE_STAMP(st, 7);
 }
 
-template <int L, int BGBIT>
+struct NoMargin {
+  __device__ __forceinline__ void track(double) {}
+};
+// Largest |x - rint(x)| seen before rounding (see polymul_kernel).
+struct Margin {
+  double all = 0.0, deciding = 0.0;
+  __device__ __forceinline__ void track(double x) {
+    const double rx = rint(x), f = fabs(x - rx);
+    all = fmax(all, f);
+    if (fabs(rx) <= 2147483648.0) deciding = fmax(deciding, f);
+  }
+};
+
+template <int L, int BGBIT, class M = NoMargin>
 __device__ __forceinline__ void extprod_accumulate(unsigned (&acc_a)[32], const cplx* __restrict__ bk,
                                                    char* wave_lds, const cplx* tE, const cplx* tw,
-                                                   int lane, StampCtx& st) {
+                                                   int lane, StampCtx& st, M&& margin = M{}) {
   const char* tt = wave_lds + kTtOff + (lane & 31) * 8;
   auto accumulate = [&](auto rc, double v) WFFT_INLINE {
     constexpr int r = decltype(rc)::value;
+    margin.track(v);
     acc_a[r] = wfft::agpr_put((unsigned)wadd((int32_t)wfft::agpr_get(acc_a[r]), wfft::round_sat_i32(v)));
   };
 #pragma unroll 1
@@ -262,21 +288,27 @@ __device__ __forceinline__ void rotate_diff(const unsigned (&acc_a)[32], int aba
     pv[32 * r] = a;
   });
   wfft::wave_lds_fence();
-  // X^abar: coefficient n comes from (n - abar) mod N, negated when it wraps
-  // (abar > 0 and n < abar) or when abar = -N (polynomial.rs:281-313).
-  const int base = q - abar;
-  const int wrap = abar > 0 ? base : (abar == -kN ? -(1 << 20) : (1 << 20));
+  // X^abar, polynomial.rs:281-313: with cycle = (abar / N) mod 2 and
+  // pw = abar % N (both truncating, as in Rust), coefficient n comes from
+  // (n - pw) mod N; it is negated when it wraps (pw > 0 and n < pw) unless cycle
+  // is set, and negated everywhere else exactly when cycle is set.
+  const MonomialPower mp = monomial_power(abar);
+  const int base = q - mp.pw;
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     v[r] = S[(base + 32 * r) & (kN - 1)];
   });
   wfft::wave_lds_fence();
-  static_for<0, 32>([&](auto ic) WFFT_INLINE {
-    constexpr int r = decltype(ic)::value;
-    const bool neg = wrap < -32 * r;
-    const int32_t x = neg ? wneg(v[r]) : v[r];
-    tt[64 * r] = (int32_t)((uint32_t)wsub(x, (int32_t)wfft::agpr_get(acc_a[r])) ^ mask);
-  });
+  auto emit = [&](auto cyc) WFFT_INLINE {
+    static_for<0, 32>([&](auto ic) WFFT_INLINE {
+      constexpr int r = decltype(ic)::value;
+      const bool neg = (base < -32 * r) != decltype(cyc)::value;
+      const int32_t x = neg ? wneg(v[r]) : v[r];
+      tt[64 * r] = (int32_t)((uint32_t)wsub(x, (int32_t)wfft::agpr_get(acc_a[r])) ^ mask);
+    });
+  };
+  if (mp.cycle) emit(std::true_type{});      // wave-uniform; rare on the bootstrap path (abar = -N)
+  else emit(std::false_type{});
   wfft::wave_lds_fence();
 }
 
@@ -448,8 +480,8 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
     // t = X^abar (prev + acc) - acc, rows r = wave, wave + W, ... of each polynomial
     // (src/bootstrapping.rs:136-146, src/polynomial.rs:281-313); then prev <- acc.
     {
-      const int base = q - abar;
-      const int wrap = abar > 0 ? base : (abar == -kN ? -(1 << 20) : (1 << 20));
+      const MonomialPower mp = monomial_power(abar);         // polynomial.rs:289-291
+      const int base = q - mp.pw;
       constexpr int kRows = (32 + W - 1) / W;
       int32_t keep[kRows];
       static_for<0, kRows>([&](auto ic) WFFT_INLINE {
@@ -460,7 +492,7 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
           const int src = (base + 32 * r) & (kN - 1);
           const int32_t v = wadd(prevL[h * kN + src], accL[h * kN + src]);
           const int32_t a = accL[h * kN + n];
-          const int32_t x = (wrap < -32 * r) ? wneg(v) : v;
+          const int32_t x = ((base < -32 * r) != mp.cycle) ? wneg(v) : v;
           ttL[2 * n + h] = (int32_t)((uint32_t)wsub(x, a) ^ kMaskTt);
           keep[e] = a;
         }
@@ -543,11 +575,13 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
 }
 
 // tgsw_extern_mul_to_tlwe on caller-supplied samples (parity hook).
-template <int L, int BGBIT>
+// margin (optional, [B][2]): the rounding margins of the 4 l products of each sample.
+template <int L, int BGBIT, bool MARGIN>
 __global__ __launch_bounds__(kBlock, 1) void extprod_kernel(const int32_t* __restrict__ t,
                                                             const cplx* __restrict__ bk_i,
                                                             const cplx* __restrict__ tables,
-                                                            int32_t* __restrict__ out, int B) {
+                                                            int32_t* __restrict__ out,
+                                                            double* __restrict__ margin, int B) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
   char* lds_tables = lds + kWavesPerBlock * wfft::kWaveBytes;
   load_tables(lds_tables, tables);
@@ -566,7 +600,20 @@ __global__ __launch_bounds__(kBlock, 1) void extprod_kernel(const int32_t* __res
     acc_a[r] = wfft::agpr_put(0u);
   });
   StampCtx st;
-  extprod_accumulate<L, BGBIT>(acc_a, bk_i, wave_tiles, tE, tw, lane, st);
+  if constexpr (MARGIN) {
+    Margin m;
+    extprod_accumulate<L, BGBIT>(acc_a, bk_i, wave_tiles, tE, tw, lane, st, m);
+    for (int off = 32; off >= 1; off >>= 1) {
+      m.all = fmax(m.all, __shfl_xor(m.all, off, 64));
+      m.deciding = fmax(m.deciding, __shfl_xor(m.deciding, off, 64));
+    }
+    if (lane == 0) {
+      margin[2 * (size_t)b + 0] = m.all;
+      margin[2 * (size_t)b + 1] = m.deciding;
+    }
+  } else {
+    extprod_accumulate<L, BGBIT>(acc_a, bk_i, wave_tiles, tE, tw, lane, st);
+  }
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     out[((size_t)b * 3 + h) * kN + q + 32 * r] = (int32_t)wfft::agpr_get(acc_a[r]);
@@ -614,11 +661,17 @@ __global__ __launch_bounds__(kBlock, 1) void bk_fft_kernel(const int32_t* __rest
 // real spectra are separated with the mirror, Z = D_a S_a + i D_b S_b, and one
 // inverse transform returns product a in the real part, product b in the
 // imaginary part.
-template <bool ACCUMULATE>
+//
+// MARGIN (test hook): nothing is written to out; margin [B][2] receives, per
+// product, the largest |x - rint(x)| over all 2N-1 coefficients before rounding
+// and the largest over the coefficients whose rounding decides the result
+// (|rint(x)| <= 2^31; beyond that the cast saturates whatever the fraction is).
+template <bool ACCUMULATE, bool MARGIN>
 __global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __restrict__ d,
                                                             const int32_t* __restrict__ s,
                                                             const cplx* __restrict__ tables,
-                                                            int32_t* __restrict__ out, int B) {
+                                                            int32_t* __restrict__ out,
+                                                            double* __restrict__ margin, int B) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
   char* lds_tables = lds + kWavesPerBlock * wfft::kWaveBytes;
   load_tables(lds_tables, tables);
@@ -692,6 +745,12 @@ __global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __res
   wfft::twist_odd_half<true>(re, im, tE, tw, q, h);
   const int prod = h ? ib : ia;        // half E ends with product a, half O with product b
   const bool live = h ? has_b : true;
+  double m_all = 0.0, m_dec = 0.0;
+  auto track = [&](double x) WFFT_INLINE {
+    const double rx = rint(x), f = fabs(x - rx);
+    m_all = fmax(m_all, f);
+    if (fabs(rx) <= 2147483648.0) m_dec = fmax(m_dec, f);
+  };
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     const int t = q + 32 * r;
@@ -700,7 +759,10 @@ __global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __res
     wfft::swap_halves(e, o);
     const double lo = e + o;
     const double hi_ = e - o;
-    if (live) {
+    if (MARGIN) {
+      track(lo);
+      if (t < kN - 1) track(hi_);
+    } else if (live) {
       if (ACCUMULATE) {
         int32_t* dst = out + (size_t)prod * kN + t;
         *dst = wadd(*dst, wfft::round_sat_i32(lo));
@@ -711,6 +773,17 @@ __global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __res
       }
     }
   });
+  if (MARGIN) {
+    // largest value of each half-wave (one product per half)
+    for (int off = 16; off >= 1; off >>= 1) {
+      m_all = fmax(m_all, __shfl_xor(m_all, off, 64));
+      m_dec = fmax(m_dec, __shfl_xor(m_dec, off, 64));
+    }
+    if (live && q == 0) {
+      margin[2 * (size_t)prod + 0] = m_all;
+      margin[2 * (size_t)prod + 1] = m_dec;
+    }
+  }
   }
 }
 
@@ -930,6 +1003,20 @@ __global__ __launch_bounds__(kKsBlock) void keyswitch_tile_kernel(
   }
 }
 
+// gates::not (src/gates.rs:122-124, src/lwe.rs:138-152): mask and body negated
+// (wrapping), variance kept.  idx runs over B * (n + 1) values.
+__global__ void not_kernel(const int32_t* __restrict__ a, const int32_t* __restrict__ b,
+                           const double* __restrict__ var, int32_t* __restrict__ out_a,
+                           int32_t* __restrict__ out_b, double* __restrict__ out_var, size_t na,
+                           size_t B) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < na) out_a[i] = wneg(a[i]);
+  else if (i < na + B) {
+    out_b[i - na] = wneg(b[i - na]);
+    if (out_var) out_var[i - na] = var ? var[i - na] : 0.0;
+  }
+}
+
 __global__ void fill_kernel(int32_t* __restrict__ p, int32_t v, size_t count) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < count) p[i] = v;
@@ -959,46 +1046,9 @@ __global__ void ks_var_zero_kernel(double* __restrict__ var, size_t rows) {
 // Host side
 // ===========================================================================
 
-struct tfhe_hip_ctx {
-  int device = 0;
-  int num_cus = 256;
-  int br_mode = TFHE_HIP_BR_AUTO;
-  hipStream_t stream = nullptr;
-  std::string err;
-  bool have_keys = false;
-  tfhe_hip_params P{};
-  int row_stride = 0;
-  cplx* tables = nullptr;        // device: tE[1024], twist[1024]
-  cplx* bkfft = nullptr;         // device blob 1
-  char* ksblob = nullptr;        // device blob 2: rows then variances
-  size_t bk_bytes = 0, ks_bytes = 0, ks_rows_bytes = 0;
-  // scratch, grown on demand
-  void* scratch = nullptr;
-  size_t scratch_bytes = 0;
-  // workspace of the circuit executor, grown on demand
-  void* work = nullptr;
-  size_t work_bytes = 0;
-  // optional per-kernel timing (tfhe_hip_profile_*)
-  bool profile = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];   // prologue, blind rotate, key switch
-};
+using tfhe_detail::fail;
 
-namespace {
-
-int fail(tfhe_hip_ctx* ctx, int code, const std::string& msg) {
-  if (ctx) ctx->err = msg;
-  return code;
-}
-
-#define HIP_TRY(ctx, expr)                                                           \
-  do {                                                                               \
-    hipError_t e_ = (expr);                                                          \
-    if (e_ != hipSuccess)                                                            \
-      return fail(ctx, TFHE_HIP_ERR_RUNTIME,                                         \
-                  std::string(#expr) + ": " + hipGetErrorString(e_));                \
-  } while (0)
-
-int check_params(tfhe_hip_ctx* ctx, const tfhe_hip_params* p) {
+int tfhe_detail::check_params(tfhe_hip_ctx* ctx, const tfhe_hip_params* p) {
   if (!p) return fail(ctx, TFHE_HIP_ERR_ARG, "params is NULL");
   if (p->N != kN || p->k != 1) return fail(ctx, TFHE_HIP_ERR_ARG, "only N=1024, k=1 is supported");
   if (!((p->l == 2 && p->bg_bit == 10) || (p->l == 3 && p->bg_bit == 7)))
@@ -1009,6 +1059,9 @@ int check_params(tfhe_hip_ctx* ctx, const tfhe_hip_params* p) {
     return fail(ctx, TFHE_HIP_ERR_ARG, "need 1 <= n <= 1020 and 1 <= n_ks <= N*k");
   return 0;
 }
+
+namespace {
+using tfhe_detail::check_params;
 
 int row_stride_of(const tfhe_hip_params* p) { return ((p->n + 1 + 3) / 4) * 4; }
 
@@ -1047,15 +1100,27 @@ struct ProfileScope {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   int kind;
   ProfileScope(tfhe_hip_ctx* c, int k) : ctx(c), kind(k) {
-    if (!ctx->profile) return;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+    // at most kMaxProfiledLaunches pairs are kept between two reads; later launches go untimed
+    if (!ctx->profile || ctx->ev[kind].size() >= kMaxProfiledLaunches) return;
+    if (hipEventCreate(&e0) != hipSuccess) { e0 = nullptr; return; }
+    if (hipEventCreate(&e1) != hipSuccess) {
+      (void)hipEventDestroy(e0);
+      e0 = e1 = nullptr;
+      return;
+    }
     (void)hipEventRecord(e0, ctx->stream);
   }
   ~ProfileScope() {
     if (!e0) return;
     (void)hipEventRecord(e1, ctx->stream);
-    ctx->ev[kind].emplace_back(e0, e1);
+    try {
+      ctx->ev[kind].emplace_back(e0, e1);
+    } catch (...) {                       // nothing may be thrown across the C ABI
+      (void)hipEventDestroy(e0);
+      (void)hipEventDestroy(e1);
+    }
   }
+  static constexpr size_t kMaxProfiledLaunches = 4096;
 };
 
 struct Weights { int wa, wb; int32_t c, mu; };
@@ -1167,6 +1232,20 @@ int launch_keyswitch(tfhe_hip_ctx* ctx, const int32_t* in_a, const int32_t* in_b
   return 0;
 }
 
+}  // namespace
+
+int tfhe_detail::need_keys(tfhe_hip_ctx* ctx) {
+  if (!ctx) return TFHE_HIP_ERR_ARG;
+  if (!ctx->shards.empty())
+    return fail(ctx, TFHE_HIP_ERR_ARG, "device-pointer entry points need a single-device context");
+  if (!ctx->have_keys) return fail(ctx, TFHE_HIP_ERR_STATE, "no keys loaded");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return 0;
+}
+
+namespace {
+using tfhe_detail::need_keys;
+
 void make_tables(std::vector<cplx>& t) {
   t.resize(2048);
   const long double two_pi = 6.283185307179586476925286766559L;
@@ -1184,12 +1263,6 @@ void make_tables(std::vector<cplx>& t) {
     }
 }
 
-int need_keys(tfhe_hip_ctx* ctx) {
-  if (!ctx) return TFHE_HIP_ERR_ARG;
-  if (!ctx->have_keys) return fail(ctx, TFHE_HIP_ERR_STATE, "no keys loaded");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  return 0;
-}
 
 // Several two-input gates with the same test-vector value mu, run as ONE
 // blind rotation over the concatenated batch (prologue and key switch per
@@ -1291,17 +1364,26 @@ int tfhe_hip_set_blind_rotate_mode(tfhe_hip_ctx* ctx, int mode) {
   if (mode != TFHE_HIP_BR_AUTO && mode != TFHE_HIP_BR_BATCH && mode != TFHE_HIP_BR_SPLIT)
     return fail(ctx, TFHE_HIP_ERR_ARG, "unknown blind-rotate mode");
   ctx->br_mode = mode;
+  for (tfhe_hip_ctx* s : ctx->shards) s->br_mode = mode;
   return 0;
 }
 
 void tfhe_hip_destroy(tfhe_hip_ctx* ctx) {
   if (!ctx) return;
+  if (!ctx->shards.empty()) {                 // multi-GPU context: owns nothing but its shards
+    for (tfhe_hip_ctx* s : ctx->shards) tfhe_hip_destroy(s);
+    delete ctx;
+    return;
+  }
   (void)hipSetDevice(ctx->device);
   if (ctx->tables) (void)hipFree(ctx->tables);
   if (ctx->bkfft) (void)hipFree(ctx->bkfft);
   if (ctx->ksblob) (void)hipFree(ctx->ksblob);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->work) (void)hipFree(ctx->work);
+  if (ctx->stage_dev) (void)hipFree(ctx->stage_dev);
+  if (ctx->stage_pin) (void)hipHostFree(ctx->stage_pin);
+  if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
   for (auto& v : ctx->ev)
     for (auto& pr : v) {
       (void)hipEventDestroy(pr.first);
@@ -1314,12 +1396,24 @@ const char* tfhe_hip_last_error(tfhe_hip_ctx* ctx) { return ctx ? ctx->err.c_str
 
 int tfhe_hip_set_stream(tfhe_hip_ctx* ctx, void* hip_stream) {
   if (!ctx) return TFHE_HIP_ERR_ARG;
+  if (!ctx->shards.empty())
+    return fail(ctx, TFHE_HIP_ERR_ARG, "a multi-GPU context runs on streams of its own");
+  if ((hipStream_t)hip_stream == ctx->stream) return 0;
+  // The context's scratch buffers are shared by every call: work still running on
+  // the old stream must finish before calls on the new one may reuse them.
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   ctx->stream = (hipStream_t)hip_stream;
   return 0;
 }
 
 int tfhe_hip_synchronize(tfhe_hip_ctx* ctx) {
   if (!ctx) return TFHE_HIP_ERR_ARG;
+  if (!ctx->shards.empty()) {
+    for (tfhe_hip_ctx* s : ctx->shards)
+      if (int rc = tfhe_hip_synchronize(s)) return fail(ctx, rc, s->err);
+    return 0;
+  }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
@@ -1328,11 +1422,22 @@ int tfhe_hip_synchronize(tfhe_hip_ctx* ctx) {
 int tfhe_hip_profile_enable(tfhe_hip_ctx* ctx, int on) {
   if (!ctx) return TFHE_HIP_ERR_ARG;
   ctx->profile = on != 0;
+  for (tfhe_hip_ctx* s : ctx->shards) s->profile = on != 0;
   return 0;
 }
 
 int tfhe_hip_profile_read(tfhe_hip_ctx* ctx, double ms_sum[3], int launches[3]) {
   if (!ctx || !ms_sum || !launches) return TFHE_HIP_ERR_ARG;
+  if (!ctx->shards.empty()) {                 // sums over the devices
+    for (int k = 0; k < 3; k++) { ms_sum[k] = 0.0; launches[k] = 0; }
+    for (tfhe_hip_ctx* s : ctx->shards) {
+      double ms[3];
+      int n[3];
+      if (int rc = tfhe_hip_profile_read(s, ms, n)) return fail(ctx, rc, s->err);
+      for (int k = 0; k < 3; k++) { ms_sum[k] += ms[k]; launches[k] += n[k]; }
+    }
+    return 0;
+  }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   for (int k = 0; k < 3; k++) {
@@ -1362,6 +1467,7 @@ int tfhe_hip_load_keys(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, const i
   if (!ctx) return TFHE_HIP_ERR_ARG;
   if (int rc = check_params(ctx, params)) return rc;
   if (!bk || !ks_a || !ks_b) return fail(ctx, TFHE_HIP_ERR_ARG, "key pointer is NULL");
+  if (!ctx->shards.empty()) return tfhe_detail::load_keys_multi(ctx, params, bk, ks_a, ks_b, ks_var);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (int rc = alloc_keys(ctx, params)) return rc;
   const tfhe_hip_params& P = ctx->P;
@@ -1419,6 +1525,8 @@ int tfhe_hip_import_keys_dev(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, c
   if (!ctx) return TFHE_HIP_ERR_ARG;
   if (int rc = check_params(ctx, params)) return rc;
   if (!bk_blob_dev || !ks_blob_dev) return fail(ctx, TFHE_HIP_ERR_ARG, "blob pointer is NULL");
+  if (!ctx->shards.empty())
+    return fail(ctx, TFHE_HIP_ERR_ARG, "device-pointer entry points need a single-device context");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (int rc = alloc_keys(ctx, params)) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->bkfft, bk_blob_dev, ctx->bk_bytes, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1499,92 +1607,10 @@ int tfhe_hip_polymul_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, 
   const unsigned grid = (unsigned)std::min<size_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock,
                                                    (size_t)ctx->num_cus);
   if (accumulate)
-    hipLaunchKernelGGL(polymul_kernel<true>, dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (int)B);
+    hipLaunchKernelGGL((polymul_kernel<true, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (double*)nullptr, (int)B);
   else
-    hipLaunchKernelGGL(polymul_kernel<false>, dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (int)B);
+    hipLaunchKernelGGL((polymul_kernel<false, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (double*)nullptr, (int)B);
   HIP_TRY(ctx, hipGetLastError());
-  return 0;
-}
-
-// ---- host-pointer entry points: stage, run, copy back ------------------------
-
-#define STAGE_IN(buf, src, bytes)                                                          \
-  DevBuf buf;                                                                              \
-  if (src) {                                                                               \
-    HIP_TRY(ctx, hipMalloc(&buf.p, (bytes)));                                              \
-    HIP_TRY(ctx, hipMemcpyAsync(buf.p, (src), (bytes), hipMemcpyHostToDevice, ctx->stream)); \
-  }
-#define STAGE_OUT(buf, bytes) \
-  DevBuf buf;                 \
-  HIP_TRY(ctx, hipMalloc(&buf.p, (bytes)));
-#define COPY_BACK(dst, buf, bytes) \
-  HIP_TRY(ctx, hipMemcpyAsync((dst), buf.p, (bytes), hipMemcpyDeviceToHost, ctx->stream));
-
-int tfhe_hip_bootstrap(tfhe_hip_ctx* ctx, int32_t mu, const int32_t* a, const int32_t* b,
-                       int32_t* out_a, int32_t* out_b, double* var_out, size_t B) {
-  if (int rc = need_keys(ctx)) return rc;
-  if (B == 0) return 0;
-  if (!a || !b || !out_a || !out_b) return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
-  const size_t n = ctx->P.n;
-  STAGE_IN(da, a, B * n * 4) STAGE_IN(db, b, B * 4)
-  STAGE_OUT(oa, B * n * 4) STAGE_OUT(ob, B * 4) STAGE_OUT(ov, B * 8)
-  if (int rc = tfhe_hip_bootstrap_dev(ctx, mu, (int32_t*)da.p, (int32_t*)db.p, (int32_t*)oa.p,
-                                      (int32_t*)ob.p, var_out ? (double*)ov.p : nullptr, B)) return rc;
-  COPY_BACK(out_a, oa, B * n * 4) COPY_BACK(out_b, ob, B * 4)
-  if (var_out) COPY_BACK(var_out, ov, B * 8)
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return 0;
-}
-
-int tfhe_hip_bootstrap_noks(tfhe_hip_ctx* ctx, int32_t mu, const int32_t* a, const int32_t* b,
-                            int32_t* out_a, int32_t* out_b, size_t B) {
-  if (int rc = need_keys(ctx)) return rc;
-  if (B == 0) return 0;
-  if (!a || !b || !out_a || !out_b) return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
-  const size_t n = ctx->P.n;
-  STAGE_IN(da, a, B * n * 4) STAGE_IN(db, b, B * 4)
-  STAGE_OUT(oa, B * kN * 4) STAGE_OUT(ob, B * 4)
-  if (int rc = tfhe_hip_bootstrap_noks_dev(ctx, mu, (int32_t*)da.p, (int32_t*)db.p, (int32_t*)oa.p,
-                                           (int32_t*)ob.p, B)) return rc;
-  COPY_BACK(out_a, oa, B * kN * 4) COPY_BACK(out_b, ob, B * 4)
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return 0;
-}
-
-int tfhe_hip_keyswitch(tfhe_hip_ctx* ctx, const int32_t* a, const int32_t* b, int32_t* out_a,
-                       int32_t* out_b, double* var_out, size_t B) {
-  if (int rc = need_keys(ctx)) return rc;
-  if (B == 0) return 0;
-  if (!a || !b || !out_a || !out_b) return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
-  const size_t n = ctx->P.n;
-  STAGE_IN(da, a, B * kN * 4) STAGE_IN(db, b, B * 4)
-  STAGE_OUT(oa, B * n * 4) STAGE_OUT(ob, B * 4) STAGE_OUT(ov, B * 8)
-  if (int rc = tfhe_hip_keyswitch_dev(ctx, (int32_t*)da.p, (int32_t*)db.p, (int32_t*)oa.p,
-                                      (int32_t*)ob.p, var_out ? (double*)ov.p : nullptr, B)) return rc;
-  COPY_BACK(out_a, oa, B * n * 4) COPY_BACK(out_b, ob, B * 4)
-  if (var_out) COPY_BACK(var_out, ov, B * 8)
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return 0;
-}
-
-int tfhe_hip_gate(tfhe_hip_ctx* ctx, int gate, const int32_t* ca_a, const int32_t* ca_b,
-                  const int32_t* cb_a, const int32_t* cb_b, const int32_t* cc_a, const int32_t* cc_b,
-                  int32_t* out_a, int32_t* out_b, double* var_out, size_t B) {
-  if (int rc = need_keys(ctx)) return rc;
-  if (B == 0) return 0;
-  if (!ca_a || !ca_b || !cb_a || !cb_b || !out_a || !out_b)
-    return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
-  const size_t n = ctx->P.n;
-  STAGE_IN(daa, ca_a, B * n * 4) STAGE_IN(dab, ca_b, B * 4)
-  STAGE_IN(dba, cb_a, B * n * 4) STAGE_IN(dbb, cb_b, B * 4)
-  STAGE_IN(dca, cc_a, B * n * 4) STAGE_IN(dcb, cc_b, B * 4)
-  STAGE_OUT(oa, B * n * 4) STAGE_OUT(ob, B * 4) STAGE_OUT(ov, B * 8)
-  if (int rc = tfhe_hip_gate_dev(ctx, gate, (int32_t*)daa.p, (int32_t*)dab.p, (int32_t*)dba.p,
-                                 (int32_t*)dbb.p, (int32_t*)dca.p, (int32_t*)dcb.p, (int32_t*)oa.p,
-                                 (int32_t*)ob.p, var_out ? (double*)ov.p : nullptr, B)) return rc;
-  COPY_BACK(out_a, oa, B * n * 4) COPY_BACK(out_b, ob, B * 4)
-  if (var_out) COPY_BACK(var_out, ov, B * 8)
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }
 
@@ -1645,77 +1671,78 @@ int tfhe_hip_circuit_add_dev(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_
   return 0;
 }
 
-int tfhe_hip_circuit_add(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_t* a_b, const int32_t* b_a,
-                         const int32_t* b_b, int32_t* sum_a, int32_t* sum_b, int32_t* carry_a,
-                         int32_t* carry_b, double* sum_var, double* carry_var, size_t count, int bits) {
+
+int tfhe_hip_not_dev(tfhe_hip_ctx* ctx, const int32_t* a, const int32_t* b, const double* var,
+                     int32_t* out_a, int32_t* out_b, double* var_out, size_t B) {
   if (int rc = need_keys(ctx)) return rc;
-  if (bits < 0) return fail(ctx, TFHE_HIP_ERR_ARG, "bits must be >= 0");
-  if (count == 0) return 0;
-  if (!carry_a || !carry_b || (bits > 0 && (!a_a || !a_b || !b_a || !b_b || !sum_a || !sum_b)))
-    return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
-  const size_t n = ctx->P.n, ma = (size_t)bits * count * n * 4, mb = (size_t)bits * count * 4;
-  STAGE_IN(daa, bits ? a_a : nullptr, ma) STAGE_IN(dab, bits ? a_b : nullptr, mb)
-  STAGE_IN(dba, bits ? b_a : nullptr, ma) STAGE_IN(dbb, bits ? b_b : nullptr, mb)
-  STAGE_OUT(dsa, std::max<size_t>(ma, 4)) STAGE_OUT(dsb, std::max<size_t>(mb, 4))
-  STAGE_OUT(dsv, std::max<size_t>(2 * mb, 8))
-  STAGE_OUT(dca, count * n * 4) STAGE_OUT(dcb, count * 4) STAGE_OUT(dcv, count * 8)
-  if (int rc = tfhe_hip_circuit_add_dev(ctx, (int32_t*)daa.p, (int32_t*)dab.p, (int32_t*)dba.p,
-                                        (int32_t*)dbb.p, (int32_t*)dsa.p, (int32_t*)dsb.p, (int32_t*)dca.p,
-                                        (int32_t*)dcb.p, sum_var ? (double*)dsv.p : nullptr,
-                                        carry_var ? (double*)dcv.p : nullptr, count, bits)) return rc;
-  if (bits) { COPY_BACK(sum_a, dsa, ma) COPY_BACK(sum_b, dsb, mb) }
-  if (bits && sum_var) COPY_BACK(sum_var, dsv, 2 * mb)
-  COPY_BACK(carry_a, dca, count * n * 4) COPY_BACK(carry_b, dcb, count * 4)
-  if (carry_var) COPY_BACK(carry_var, dcv, count * 8)
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return 0;
-}
-
-int tfhe_hip_polymul(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, int32_t* out,
-                     int accumulate, size_t B) {
-  if (!ctx) return TFHE_HIP_ERR_ARG;
   if (B == 0) return 0;
-  if (!d || !s || !out) return fail(ctx, TFHE_HIP_ERR_ARG, "polynomial pointer is NULL");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const size_t out_bytes = B * (accumulate ? kN : 2 * kN - 1) * sizeof(int32_t);
-  STAGE_IN(dd, d, B * kN * 4) STAGE_IN(ds, s, B * kN * 4)
-  STAGE_IN(dout, out, out_bytes)
-  if (int rc = tfhe_hip_polymul_dev(ctx, (int32_t*)dd.p, (int32_t*)ds.p, (int32_t*)dout.p, accumulate, B)) return rc;
-  COPY_BACK(out, dout, out_bytes)
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  if (!a || !b || !out_a || !out_b) return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
+  const size_t na = B * (size_t)ctx->P.n, total = na + B;
+  hipLaunchKernelGGL(not_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, a, b, var,
+                     out_a, out_b, var_out, na, B);
+  HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
 
-int tfhe_hip_extprod(tfhe_hip_ctx* ctx, const int32_t* t, int bk_index, int32_t* out, size_t B) {
+int tfhe_hip_constant_dev(tfhe_hip_ctx* ctx, int value, int32_t* out_a, int32_t* out_b,
+                          double* var_out, size_t B) {
+  if (int rc = need_keys(ctx)) return rc;
+  if (B == 0) return 0;
+  if (!out_a || !out_b) return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
+  // LweSample::trivial(encode_message(+-1, 8)), src/gates.rs:12-20: zero mask, variance 0
+  HIP_TRY(ctx, hipMemsetAsync(out_a, 0, B * (size_t)ctx->P.n * sizeof(int32_t), ctx->stream));
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, ctx->stream, out_b,
+                     value ? (1 << 29) : -(1 << 29), B);
+  HIP_TRY(ctx, hipGetLastError());
+  if (var_out) HIP_TRY(ctx, hipMemsetAsync(var_out, 0, B * sizeof(double), ctx->stream));
+  return 0;
+}
+
+int tfhe_hip_polymul_margin_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, double* margin,
+                                size_t B) {
+  if (!ctx) return TFHE_HIP_ERR_ARG;
+  if (!ctx->shards.empty())
+    return fail(ctx, TFHE_HIP_ERR_ARG, "device-pointer entry points need a single-device context");
+  if (B == 0) return 0;
+  if (!d || !s || !margin) return fail(ctx, TFHE_HIP_ERR_ARG, "polynomial pointer is NULL");
+  if (B > (size_t)INT32_MAX) return fail(ctx, TFHE_HIP_ERR_ARG, "batch too large");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t pairs = (B + 1) / 2;
+  const unsigned grid = (unsigned)std::min<size_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock,
+                                                   (size_t)ctx->num_cus);
+  hipLaunchKernelGGL((polymul_kernel<false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s,
+                     ctx->tables, (int32_t*)nullptr, margin, (int)B);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int tfhe_hip_extprod_dev(tfhe_hip_ctx* ctx, const int32_t* t, int bk_index, int32_t* out,
+                         double* margin, size_t B) {
   if (int rc = need_keys(ctx)) return rc;
   if (B == 0) return 0;
   if (!t || !out) return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
   if (bk_index < 0 || bk_index >= ctx->P.n) return fail(ctx, TFHE_HIP_ERR_ARG, "bk_index out of range");
-  const size_t bytes = B * 3 * kN * sizeof(int32_t);
-  STAGE_IN(dt, t, bytes) STAGE_OUT(dout, bytes)
+  if (B > (size_t)INT32_MAX) return fail(ctx, TFHE_HIP_ERR_ARG, "batch too large");
   const cplx* bk_i = ctx->bkfft + (size_t)bk_index * ctx->P.l * 2 * 2048;
-  const unsigned grid = (unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock);
-  if (ctx->P.l == 2)
-    hipLaunchKernelGGL((extprod_kernel<2, 10>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const int32_t*)dt.p, bk_i, ctx->tables, (int32_t*)dout.p, (int)B);
-  else
-    hipLaunchKernelGGL((extprod_kernel<3, 7>), dim3(grid), dim3(kBlock), 0, ctx->stream, (const int32_t*)dt.p, bk_i, ctx->tables, (int32_t*)dout.p, (int)B);
+  const dim3 grid((unsigned)((B + kWavesPerBlock - 1) / kWavesPerBlock)), block(kBlock);
+  const bool l2 = ctx->P.l == 2;
+  if (margin) {
+    if (l2) hipLaunchKernelGGL((extprod_kernel<2, 10, true>), grid, block, 0, ctx->stream, t, bk_i, ctx->tables, out, margin, (int)B);
+    else hipLaunchKernelGGL((extprod_kernel<3, 7, true>), grid, block, 0, ctx->stream, t, bk_i, ctx->tables, out, margin, (int)B);
+  } else {
+    if (l2) hipLaunchKernelGGL((extprod_kernel<2, 10, false>), grid, block, 0, ctx->stream, t, bk_i, ctx->tables, out, margin, (int)B);
+    else hipLaunchKernelGGL((extprod_kernel<3, 7, false>), grid, block, 0, ctx->stream, t, bk_i, ctx->tables, out, margin, (int)B);
+  }
   HIP_TRY(ctx, hipGetLastError());
-  COPY_BACK(out, dout, bytes)
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   return 0;
 }
 
-int tfhe_hip_blind_rotate(tfhe_hip_ctx* ctx, int32_t* acc, const int32_t* bara, size_t B) {
+int tfhe_hip_blind_rotate_dev(tfhe_hip_ctx* ctx, int32_t* acc, const int32_t* bara, size_t B) {
   if (int rc = need_keys(ctx)) return rc;
   if (B == 0) return 0;
   if (!acc || !bara) return fail(ctx, TFHE_HIP_ERR_ARG, "pointer is NULL");
-  const size_t bytes = B * 3 * kN * sizeof(int32_t);
-  STAGE_IN(dacc, acc, bytes) STAGE_IN(dbara, bara, B * ctx->P.n * 4)
-  if (int rc = launch_blind_rotate(ctx, (int32_t*)dbara.p, nullptr, 0, (int32_t*)dacc.p, nullptr,
-                                   nullptr, B)) return rc;
-  COPY_BACK(acc, dacc, bytes)
-  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  return 0;
+  if (B > (size_t)INT32_MAX) return fail(ctx, TFHE_HIP_ERR_ARG, "batch too large");
+  return launch_blind_rotate(ctx, bara, nullptr, 0, acc, nullptr, nullptr, B);
 }
 
 }  // extern "C"

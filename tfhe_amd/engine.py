@@ -1,8 +1,11 @@
 """Thin Python handle over the C ABI (include/tfhe_hip.h).
 
-``Engine`` owns one ``tfhe_hip_ctx`` on one GPU.  Methods taking numpy arrays use
-the host-pointer entry points; the ``*_dev`` methods take torch CUDA tensors,
-run on torch's current stream and do not synchronise.
+``Engine`` owns one ``tfhe_hip_ctx`` on one GPU (``Engine(0)``) or on a list of
+GPUs (``Engine([0, 1, 2, 3])``, tfhe_hip_create_multi).  Methods taking numpy
+arrays use the host-pointer entry points; the ``*_dev`` methods take torch CUDA
+tensors, run on torch's current stream and do not synchronise (single-GPU
+engines only).  Every array is checked against the batch size and the loaded
+parameters before its pointer crosses the boundary.
 """
 import ctypes as C
 
@@ -34,11 +37,59 @@ def _tp(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+def _want(arr, shape, what):
+    if tuple(arr.shape) != tuple(shape):
+        raise ValueError(f"{what}: expected shape {tuple(shape)}, got {tuple(arr.shape)}")
+    return arr
+
+
+class Samples:
+    """Device-resident batch of LWE samples (tfhe_hip_samples)."""
+
+    def __init__(self, engine, B):
+        self.engine = engine
+        self.handle = C.c_void_p()
+        engine._check(engine.lib.tfhe_hip_samples_alloc(engine.ctx, B, C.byref(self.handle)))
+        self.B = B
+
+    def free(self):
+        if self.handle:
+            self.engine.lib.tfhe_hip_samples_free(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            if self.engine.ctx:
+                self.free()
+        except Exception:
+            pass
+
+    def upload(self, a, b, var=None):
+        e = self.engine
+        a = _want(_np(a), (self.B, e.params.n), "a")
+        b = _want(_np(b), (self.B,), "b")
+        var = None if var is None else _want(_np(var, np.float64), (self.B,), "var")
+        e._check(e.lib.tfhe_hip_samples_upload(e.ctx, self.handle, _p(a), _p(b), _p(var)))
+        return self
+
+    def download(self, want_var=False):
+        e = self.engine
+        a = np.empty((self.B, e.params.n), np.int32)
+        b = np.empty(self.B, np.int32)
+        var = np.empty(self.B, np.float64) if want_var else None
+        e._check(e.lib.tfhe_hip_samples_download(e.ctx, self.handle, _p(a), _p(b), _p(var)))
+        return (a, b, var) if want_var else (a, b)
+
+
 class Engine:
     def __init__(self, device=0):
         self.lib = _lib.load()
         self.ctx = C.c_void_p()
-        rc = self.lib.tfhe_hip_create(C.byref(self.ctx), device)
+        if isinstance(device, (list, tuple)):
+            devs = (C.c_int * len(device))(*device)
+            rc = self.lib.tfhe_hip_create_multi(C.byref(self.ctx), devs, len(device))
+        else:
+            rc = self.lib.tfhe_hip_create(C.byref(self.ctx), device)
         if rc != 0:
             raise TfheHipError(f"tfhe_hip_create failed ({rc}): no usable GPU {device}")
         self.device = device
@@ -59,15 +110,48 @@ class Engine:
         if rc != 0:
             raise TfheHipError(f"{rc}: {self.lib.tfhe_hip_last_error(self.ctx).decode()}")
 
+    def last_message(self):
+        return self.lib.tfhe_hip_last_error(self.ctx).decode()
+
     # ---- keys -----------------------------------------------------------------
-    def load_keys(self, params, bk, ks_a, ks_b, ks_var=None):
-        bk, ks_a, ks_b = _np(bk), _np(ks_a), _np(ks_b)
+    @staticmethod
+    def _key_arrays(params, bk, ks_a, ks_b, ks_var):
+        base = 1 << params.ks_base_bit
+        bk = _np(bk)
+        ks_a, ks_b = _np(ks_a), _np(ks_b)
         ks_var = None if ks_var is None else _np(ks_var, np.float64)
-        assert bk.size == params.n * params.l * (params.k + 1) ** 2 * params.N
-        assert ks_a.size == params.n_ks * params.ks_t * (1 << params.ks_base_bit) * params.n
+        rows = params.n_ks * params.ks_t * base
+        if bk.size != params.n * params.l * (params.k + 1) ** 2 * params.N:
+            raise ValueError("bk does not match the parameters")
+        if ks_a.size != rows * params.n or ks_b.size != rows:
+            raise ValueError("ks_a / ks_b do not match the parameters")
+        if ks_var is not None and ks_var.size != rows:
+            raise ValueError("ks_var does not match the parameters")
+        return bk, ks_a, ks_b, ks_var
+
+    def load_keys(self, params, bk, ks_a, ks_b, ks_var=None):
+        bk, ks_a, ks_b, ks_var = self._key_arrays(params, bk, ks_a, ks_b, ks_var)
         self._check(self.lib.tfhe_hip_load_keys(self.ctx, C.byref(params), _p(bk), _p(ks_a),
                                                 _p(ks_b), _p(ks_var)))
         self.params = params
+
+    def pack_key_file(self, params, bk, ks_a, ks_b, ks_var=None):
+        """The flat key image (bytes) that load_key_file / tfhe_hip_load_keys_blob read."""
+        bk, ks_a, ks_b, ks_var = self._key_arrays(params, bk, ks_a, ks_b, ks_var)
+        size = C.c_size_t()
+        if self.lib.tfhe_hip_key_file_size(C.byref(params), int(ks_var is not None), C.byref(size)) != 0:
+            raise TfheHipError("unsupported parameters")
+        out = np.empty(size.value, np.uint8)
+        if self.lib.tfhe_hip_key_file_pack(C.byref(params), _p(bk), _p(ks_a), _p(ks_b), _p(ks_var),
+                                           _p(out), out.size) != 0:
+            raise TfheHipError("tfhe_hip_key_file_pack failed")
+        return out
+
+    def load_key_file(self, image):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        self._check(self.lib.tfhe_hip_load_keys_blob(self.ctx, _p(image), image.size))
+        f = np.frombuffer(image[16:48].tobytes(), dtype=np.int32)
+        self.params = _lib.Params(*[int(x) for x in f])
 
     def key_blob_sizes(self, params=None):
         params = params or self.params
@@ -78,9 +162,15 @@ class Engine:
         return a.value, b.value
 
     def export_keys_dev(self, bk_blob, ks_blob):
+        bk_bytes, ks_bytes = self.key_blob_sizes()
+        if bk_blob.numel() * bk_blob.element_size() < bk_bytes or ks_blob.numel() * ks_blob.element_size() < ks_bytes:
+            raise ValueError("key blob buffers are too small")
         self._check(self.lib.tfhe_hip_export_keys_dev(self.ctx, _tp(bk_blob), _tp(ks_blob)))
 
     def import_keys_dev(self, params, bk_blob, ks_blob):
+        bk_bytes, ks_bytes = self.key_blob_sizes(params)
+        if bk_blob.numel() * bk_blob.element_size() < bk_bytes or ks_blob.numel() * ks_blob.element_size() < ks_bytes:
+            raise ValueError("key blob buffers are too small")
         self._check(self.lib.tfhe_hip_import_keys_dev(self.ctx, C.byref(params), _tp(bk_blob),
                                                       _tp(ks_blob)))
         self.params = params
@@ -109,9 +199,14 @@ class Engine:
         self._check(self.lib.tfhe_hip_synchronize(self.ctx))
 
     # ---- host-pointer path ------------------------------------------------------
+    def _sample(self, pair, B, width, what):
+        a, b = _np(pair[0]), _np(pair[1])
+        if B is None:
+            B = b.size
+        return _want(a, (B, width), what + " mask"), _want(b.reshape(-1), (B,), what + " body"), B
+
     def bootstrap(self, mu, a, b, want_var=False):
-        a, b = _np(a), _np(b)
-        B = b.size
+        a, b, B = self._sample((a, b), None, self.params.n, "x")
         out_a = np.empty((B, self.params.n), np.int32)
         out_b = np.empty(B, np.int32)
         var = np.empty(B, np.float64) if want_var else None
@@ -120,8 +215,7 @@ class Engine:
         return (out_a, out_b, var) if want_var else (out_a, out_b)
 
     def bootstrap_noks(self, mu, a, b):
-        a, b = _np(a), _np(b)
-        B = b.size
+        a, b, B = self._sample((a, b), None, self.params.n, "x")
         out_a = np.empty((B, self.params.N * self.params.k), np.int32)
         out_b = np.empty(B, np.int32)
         self._check(self.lib.tfhe_hip_bootstrap_noks(self.ctx, mu, _p(a), _p(b), _p(out_a),
@@ -129,8 +223,7 @@ class Engine:
         return out_a, out_b
 
     def keyswitch(self, a, b, want_var=False):
-        a, b = _np(a), _np(b)
-        B = b.size
+        a, b, B = self._sample((a, b), None, self.params.N * self.params.k, "x")
         out_a = np.empty((B, self.params.n), np.int32)
         out_b = np.empty(B, np.int32)
         var = np.empty(B, np.float64) if want_var else None
@@ -140,11 +233,13 @@ class Engine:
 
     def gate(self, gate, ca, cb, cc=None, want_var=False):
         """ca, cb, cc: (a [B][n], b [B]) pairs."""
-        ca_a, ca_b, cb_a, cb_b = _np(ca[0]), _np(ca[1]), _np(cb[0]), _np(cb[1])
-        cc_a = None if cc is None else _np(cc[0])
-        cc_b = None if cc is None else _np(cc[1])
-        B = ca_b.size
-        out_a = np.empty((B, self.params.n), np.int32)
+        n = self.params.n
+        ca_a, ca_b, B = self._sample(ca, None, n, "ca")
+        cb_a, cb_b, _ = self._sample(cb, B, n, "cb")
+        cc_a = cc_b = None
+        if cc is not None:
+            cc_a, cc_b, _ = self._sample(cc, B, n, "cc")
+        out_a = np.empty((B, n), np.int32)
         out_b = np.empty(B, np.int32)
         var = np.empty(B, np.float64) if want_var else None
         self._check(self.lib.tfhe_hip_gate(self.ctx, GATE_ID[gate], _p(ca_a), _p(ca_b), _p(cb_a),
@@ -157,8 +252,13 @@ class Engine:
         bit 0 first.  Returns (sum, carry[, sum_var, carry_var]) with sum = (masks, bodies) in the
         same layout and carry = ([count][n], [count])."""
         a_a, a_b, b_a, b_b = _np(a[0]), _np(a[1]), _np(b[0]), _np(b[1])
+        if a_b.ndim != 2:
+            raise ValueError("bodies must be [bits][count]")
         bits, count = a_b.shape
         n = self.params.n
+        _want(a_a, (bits, count, n), "a masks")
+        _want(b_a, (bits, count, n), "b masks")
+        _want(b_b, (bits, count), "b bodies")
         sum_a, sum_b = np.empty((bits, count, n), np.int32), np.empty((bits, count), np.int32)
         car_a, car_b = np.empty((count, n), np.int32), np.empty(count, np.int32)
         sv = np.empty((bits, count), np.float64) if want_var else None
@@ -172,45 +272,114 @@ class Engine:
 
     def polymul(self, d, s, accumulate_into=None):
         d, s = _np(d), _np(s)
+        if d.ndim != 2 or d.shape[1] != 1024:
+            raise ValueError("d must be [B][1024]")
         B = d.shape[0]
+        _want(s, (B, 1024), "s")
         if accumulate_into is None:
             out = np.empty((B, 2 * d.shape[1] - 1), np.int32)
             acc = 0
         else:
-            out = np.array(accumulate_into, dtype=np.int32, order="C")
+            out = _want(np.array(accumulate_into, dtype=np.int32, order="C"), (B, 1024), "accumulate_into")
             acc = 1
         self._check(self.lib.tfhe_hip_polymul(self.ctx, _p(d), _p(s), _p(out), acc, B))
         return out
 
-    def extprod(self, t, bk_index):
+    def polymul_margin(self, d, s):
+        """[B][2]: largest |x - rint(x)| before rounding, over all coefficients and over those
+        whose rounding decides the result, measured in the product kernel itself."""
+        d, s = _np(d), _np(s)
+        if d.ndim != 2 or d.shape[1] != 1024:
+            raise ValueError("d must be [B][1024]")
+        B = d.shape[0]
+        _want(s, (B, 1024), "s")
+        m = np.empty((B, 2), np.float64)
+        self._check(self.lib.tfhe_hip_polymul_margin(self.ctx, _p(d), _p(s), _p(m), B))
+        return m
+
+    def extprod(self, t, bk_index, want_margin=False):
         t = _np(t)
+        if t.ndim != 3 or t.shape[1:] != (3, 1024):
+            raise ValueError("t must be [B][3][1024]")
         out = np.empty_like(t)
-        self._check(self.lib.tfhe_hip_extprod(self.ctx, _p(t), bk_index, _p(out), t.shape[0]))
-        return out
+        if not want_margin:
+            self._check(self.lib.tfhe_hip_extprod(self.ctx, _p(t), bk_index, _p(out), t.shape[0]))
+            return out
+        m = np.empty((t.shape[0], 2), np.float64)
+        self._check(self.lib.tfhe_hip_extprod_margin(self.ctx, _p(t), bk_index, _p(out), _p(m), t.shape[0]))
+        return out, m
 
     def blind_rotate(self, acc, bara):
         acc = np.array(acc, dtype=np.int32, order="C")
-        bara = _np(bara)
+        if acc.ndim != 3 or acc.shape[1:] != (3, 1024):
+            raise ValueError("acc must be [B][3][1024]")
+        bara = _want(_np(bara), (acc.shape[0], self.params.n), "bara")
         self._check(self.lib.tfhe_hip_blind_rotate(self.ctx, _p(acc), _p(bara), acc.shape[0]))
         return acc
 
+    # ---- device-resident sample handles -------------------------------------------
+    def samples(self, B):
+        return Samples(self, B)
+
+    def samples_from(self, a, b, var=None):
+        b = _np(b).reshape(-1)
+        return Samples(self, b.size).upload(a, b, var)
+
+    def samples_gate(self, gate, ca, cb, out, cc=None):
+        self._check(self.lib.tfhe_hip_samples_gate(self.ctx, GATE_ID[gate], ca.handle, cb.handle,
+                                                   cc.handle if cc is not None else None, out.handle))
+        return out
+
+    def samples_bootstrap(self, mu, x, out):
+        self._check(self.lib.tfhe_hip_samples_bootstrap(self.ctx, mu, x.handle, out.handle))
+        return out
+
+    def samples_not(self, x, out):
+        self._check(self.lib.tfhe_hip_samples_not(self.ctx, x.handle, out.handle))
+        return out
+
+    def samples_constant(self, value, out):
+        self._check(self.lib.tfhe_hip_samples_constant(self.ctx, int(bool(value)), out.handle))
+        return out
+
     # ---- device-pointer path (torch tensors on this engine's GPU) -----------------
+    def _dev_sample(self, a, b, B, width, what):
+        if a.numel() != B * width or b.numel() != B:
+            raise ValueError(f"{what}: expected [{B}][{width}] and [{B}]")
+
     def gate_dev(self, gate, ca_a, ca_b, cb_a, cb_b, out_a, out_b, cc_a=None, cc_b=None, var=None):
+        B, n = ca_b.numel(), self.params.n
+        self._dev_sample(ca_a, ca_b, B, n, "ca")
+        self._dev_sample(cb_a, cb_b, B, n, "cb")
+        self._dev_sample(out_a, out_b, B, n, "out")
+        if cc_a is not None:
+            self._dev_sample(cc_a, cc_b, B, n, "cc")
         self._check(self.lib.tfhe_hip_gate_dev(self.ctx, GATE_ID[gate], _tp(ca_a), _tp(ca_b),
                                                _tp(cb_a), _tp(cb_b), _tp(cc_a), _tp(cc_b),
-                                               _tp(out_a), _tp(out_b), _tp(var), ca_b.numel()))
+                                               _tp(out_a), _tp(out_b), _tp(var), B))
 
     def circuit_add_dev(self, a_a, a_b, b_a, b_b, sum_a, sum_b, carry_a, carry_b, sum_var=None,
                         carry_var=None):
         bits, count = a_b.shape
+        n = self.params.n
+        for t, w in ((a_a, n), (b_a, n), (sum_a, n), (a_b, 1), (b_b, 1), (sum_b, 1)):
+            if t.numel() != bits * count * w:
+                raise ValueError("operand shapes differ")
+        self._dev_sample(carry_a, carry_b, count, n, "carry")
         self._check(self.lib.tfhe_hip_circuit_add_dev(
             self.ctx, _tp(a_a), _tp(a_b), _tp(b_a), _tp(b_b), _tp(sum_a), _tp(sum_b), _tp(carry_a),
             _tp(carry_b), _tp(sum_var), _tp(carry_var), count, bits))
 
     def bootstrap_dev(self, mu, a, b, out_a, out_b, var=None):
+        B, n = b.numel(), self.params.n
+        self._dev_sample(a, b, B, n, "x")
+        self._dev_sample(out_a, out_b, B, n, "out")
         self._check(self.lib.tfhe_hip_bootstrap_dev(self.ctx, mu, _tp(a), _tp(b), _tp(out_a),
-                                                    _tp(out_b), _tp(var), b.numel()))
+                                                    _tp(out_b), _tp(var), B))
 
     def polymul_dev(self, d, s, out, accumulate=False):
+        B = d.shape[0]
+        if d.numel() != B * 1024 or s.numel() != B * 1024 or out.numel() != B * (1024 if accumulate else 2047):
+            raise ValueError("polynomial shapes differ")
         self._check(self.lib.tfhe_hip_polymul_dev(self.ctx, _tp(d), _tp(s), _tp(out),
-                                                  int(accumulate), d.shape[0]))
+                                                  int(accumulate), B))

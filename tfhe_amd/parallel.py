@@ -32,8 +32,12 @@ def replicate_keys(engine, params, device, src=0, group=None):
     """After `engine.load_keys` on rank `src`, gives every rank the same device keys.
 
     engine: tfhe_amd.Engine of this rank; params: tfhe_hip_params (same on all ranks).
+    src is a GLOBAL rank (as torch.distributed.broadcast takes it), also when `group` is a
+    sub-group.
     """
-    rank = dist.get_rank(group)
+    rank = dist.get_rank()          # global, to compare with src
+    if group is not None and src not in dist.get_process_group_ranks(group):
+        raise ValueError("src must be a member of the group")
     bk_bytes, ks_bytes = engine.key_blob_sizes(params)
     bk_blob = torch.empty(bk_bytes, dtype=torch.uint8, device=device)
     ks_blob = torch.empty(ks_bytes, dtype=torch.uint8, device=device)
