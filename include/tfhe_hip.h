@@ -186,6 +186,25 @@ int tfhe_hip_gate_dev(tfhe_hip_ctx* ctx, int gate, const int32_t* ca_a, const in
                       const int32_t* cc_b, int32_t* out_a, int32_t* out_b, double* var_out,
                       size_t B);
 
+/* tfhe_hip_gate_dev for callers that cannot allocate (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No
+ * counterpart in the reference.  Same arguments and results as
+ * tfhe_hip_gate_dev, but the scratch of the call (mod-switched operands,
+ * extracted samples: about 4 n + 4 224 bytes per ciphertext, twice that per mux
+ * gate) lives in a fixed 4 MiB array inside the library instead of the context's
+ * grown-on-demand pool, and nothing is allocated or freed: no hipMalloc, no
+ * hipFree, no events.  Limits: the batch must fit the array (668 gates or 334
+ * mux gates at n = 500; 618 / 309 at n = 630), larger batches fail with
+ * TFHE_HIP_ERR_ARG and a message that states the limit; keys must be loaded
+ * before.  Every GPU the library runs on holds one copy of the array until the
+ * process ends, and every call on that GPU (from any context) uses it: calls that
+ * overlap on one GPU race.  Nothing in it needs to start at zero (each call
+ * writes every entry before reading it). */
+int tfhe_hip_gate_dev_noalloc(tfhe_hip_ctx* ctx, int gate, const int32_t* ca_a, const int32_t* ca_b,
+                              const int32_t* cb_a, const int32_t* cb_b, const int32_t* cc_a,
+                              const int32_t* cc_b, int32_t* out_a, int32_t* out_b, double* var_out,
+                              size_t B);
+
 /* gates::not (src/gates.rs:122-124: mask and body negated, variance kept; `var`
  * may be NULL = zeros) and gates::constant (src/gates.rs:12-20: the noiseless
  * trivial sample of +-1/8) on device buffers. */

@@ -26,7 +26,7 @@ SYMBOLS = [
     "tfhe_hip_samples_download", "tfhe_hip_samples_gate", "tfhe_hip_samples_bootstrap",
     "tfhe_hip_samples_not", "tfhe_hip_samples_constant",
     "tfhe_hip_polymul_margin", "tfhe_hip_polymul_margin_dev", "tfhe_hip_extprod_margin",
-    "tfhe_hip_extprod_dev", "tfhe_hip_blind_rotate_dev",
+    "tfhe_hip_extprod_dev", "tfhe_hip_blind_rotate_dev", "tfhe_hip_gate_dev_noalloc",
 ]
 NO_INT_RESULT = ("tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_samples_free", "tfhe_hip_samples_count")
 
@@ -67,7 +67,7 @@ def load():
         getattr(lib, name).argtypes = [vp, C.c_int32, i32p, i32p, i32p, i32p, sz]
     for name in ("tfhe_hip_keyswitch", "tfhe_hip_keyswitch_dev"):
         getattr(lib, name).argtypes = [vp, i32p, i32p, i32p, i32p, f64p, sz]
-    for name in ("tfhe_hip_gate", "tfhe_hip_gate_dev"):
+    for name in ("tfhe_hip_gate", "tfhe_hip_gate_dev", "tfhe_hip_gate_dev_noalloc"):
         getattr(lib, name).argtypes = [vp, C.c_int, i32p, i32p, i32p, i32p, i32p, i32p, i32p, i32p,
                                        f64p, sz]
     for name in ("tfhe_hip_polymul", "tfhe_hip_polymul_dev"):

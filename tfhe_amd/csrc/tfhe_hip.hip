@@ -1042,6 +1042,14 @@ __global__ void ks_var_zero_kernel(double* __restrict__ var, size_t rows) {
 
 }  // namespace
 
+// Scratch of tfhe_hip_gate_dev_noalloc, the entry point that allocates nothing:
+// mod-switched operands and extracted samples of one call (the layout of
+// get_scratch).  Every GPU the library runs on holds its own copy of this array
+// until the process ends; host code reaches it only through the per-device
+// address that tfhe_hip_create obtains with hipGetSymbolAddress.
+constexpr size_t kFixedScratchBytes = (size_t)4 << 20;
+static __device__ __align__(256) unsigned char scratch[kFixedScratchBytes];
+
 // ===========================================================================
 // Host side
 // ===========================================================================
@@ -1148,15 +1156,20 @@ struct Scratch {
   int32_t *bara, *barb, *ea, *eb;
 };
 
-int get_scratch(tfhe_hip_ctx* ctx, size_t B, Scratch* s) {
-  const size_t n = ctx->P.n;
+// Lays the four arrays out behind `base`; returns the bytes they take.
+size_t scratch_layout(size_t n, size_t B, char* base, Scratch* s) {
   auto up = [](size_t x) { return (x + 63) / 64 * 64; };
   const size_t o_bara = 0, o_barb = o_bara + up(B * n * 4);
   const size_t o_ea = o_barb + up(B * 4), o_eb = o_ea + up(B * kN * 4), total = o_eb + up(B * 4);
-  if (int rc = ensure_scratch(ctx, total)) return rc;
-  char* base = (char*)ctx->scratch;
   s->bara = (int32_t*)(base + o_bara); s->barb = (int32_t*)(base + o_barb);
   s->ea = (int32_t*)(base + o_ea); s->eb = (int32_t*)(base + o_eb);
+  return total;
+}
+
+int get_scratch(tfhe_hip_ctx* ctx, size_t B, Scratch* s) {
+  const size_t total = scratch_layout(ctx->P.n, B, nullptr, s);
+  if (int rc = ensure_scratch(ctx, total)) return rc;
+  scratch_layout(ctx->P.n, B, (char*)ctx->scratch, s);
   return 0;
 }
 
@@ -1348,6 +1361,11 @@ int tfhe_hip_create(tfhe_hip_ctx** out, int device) {
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
     ctx->num_cus = cus;
+  // this device's copy of the fixed scratch array (the device is current)
+  if (hipGetSymbolAddress(&ctx->fixed_scratch, HIP_SYMBOL(scratch)) != hipSuccess || !ctx->fixed_scratch) {
+    delete ctx;
+    return TFHE_HIP_ERR_RUNTIME;
+  }
   std::vector<cplx> t;
   make_tables(t);
   if (hipMalloc((void**)&ctx->tables, t.size() * sizeof(cplx)) != hipSuccess ||
@@ -1567,19 +1585,38 @@ int tfhe_hip_bootstrap_dev(tfhe_hip_ctx* ctx, int32_t mu, const int32_t* a, cons
   return launch_keyswitch(ctx, s.ea, s.eb, nullptr, nullptr, 0, out_a, out_b, var_out, B);
 }
 
-int tfhe_hip_gate_dev(tfhe_hip_ctx* ctx, int gate, const int32_t* ca_a, const int32_t* ca_b,
-                      const int32_t* cb_a, const int32_t* cb_b, const int32_t* cc_a,
-                      const int32_t* cc_b, int32_t* out_a, int32_t* out_b, double* var_out, size_t B) {
+}  // extern "C"
+
+namespace {
+
+// The gate on device buffers.  fixed = false: scratch from the context's pool
+// (grown with hipMalloc on demand); fixed = true: the library's fixed scratch
+// array, no allocation of any kind.
+int gate_on_device(tfhe_hip_ctx* ctx, bool fixed, int gate, const int32_t* ca_a, const int32_t* ca_b,
+                   const int32_t* cb_a, const int32_t* cb_b, const int32_t* cc_a, const int32_t* cc_b,
+                   int32_t* out_a, int32_t* out_b, double* var_out, size_t B) {
   if (int rc = need_keys(ctx)) return rc;
   if (B == 0) return 0;
   if (!ca_a || !ca_b || !cb_a || !cb_b || !out_a || !out_b)
     return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
   Scratch s;
+  auto take_scratch = [&](size_t count) -> int {
+    if (!fixed) return get_scratch(ctx, count, &s);
+    if (!ctx->fixed_scratch) return fail(ctx, TFHE_HIP_ERR_STATE, "the fixed scratch array is unavailable");
+    const size_t per = scratch_layout(ctx->P.n, 1, nullptr, &s);
+    if (count > kFixedScratchBytes / per || scratch_layout(ctx->P.n, count, nullptr, &s) > kFixedScratchBytes)
+      return fail(ctx, TFHE_HIP_ERR_ARG,
+                  "batch too large for the fixed scratch (" + std::to_string(kFixedScratchBytes >> 20) +
+                      " MiB): at most about " + std::to_string(kFixedScratchBytes / per) +
+                      " ciphertexts per call with these parameters, half as many mux gates");
+    scratch_layout(ctx->P.n, count, (char*)ctx->fixed_scratch, &s);
+    return 0;
+  };
   if (gate == TFHE_HIP_MUX) {                                 // src/gates.rs:239-268
     if (!cc_a || !cc_b) return fail(ctx, TFHE_HIP_ERR_ARG, "mux needs a third operand");
     // u1 = bootstrap_noks(and(a, b)), u2 = bootstrap_noks(andny(a, c)) share mu and run as ONE
     // blind rotation over 2 B ciphertexts; the key switch then takes trivial(1/8) + u1 + u2.
-    if (int rc = get_scratch(ctx, 2 * B, &s)) return rc;
+    if (int rc = take_scratch(2 * B)) return rc;
     Weights w1, w2;
     gate_weights(TFHE_HIP_AND, &w1);
     gate_weights(TFHE_HIP_ANDNY, &w2);
@@ -1591,10 +1628,33 @@ int tfhe_hip_gate_dev(tfhe_hip_ctx* ctx, int gate, const int32_t* ca_a, const in
   }
   Weights w;
   if (!gate_weights(gate, &w)) return fail(ctx, TFHE_HIP_ERR_ARG, "unknown gate id");
-  if (int rc = get_scratch(ctx, B, &s)) return rc;
+  if (int rc = take_scratch(B)) return rc;
   if (int rc = launch_prologue(ctx, ca_a, ca_b, cb_a, cb_b, w.wa, w.wb, w.c, B, s.bara, s.barb)) return rc;
   if (int rc = launch_blind_rotate(ctx, s.bara, s.barb, w.mu, nullptr, s.ea, s.eb, B)) return rc;
   return launch_keyswitch(ctx, s.ea, s.eb, nullptr, nullptr, 0, out_a, out_b, var_out, B);
+}
+
+}  // namespace
+
+extern "C" {
+
+int tfhe_hip_gate_dev(tfhe_hip_ctx* ctx, int gate, const int32_t* ca_a, const int32_t* ca_b,
+                      const int32_t* cb_a, const int32_t* cb_b, const int32_t* cc_a,
+                      const int32_t* cc_b, int32_t* out_a, int32_t* out_b, double* var_out, size_t B) {
+  return gate_on_device(ctx, false, gate, ca_a, ca_b, cb_a, cb_b, cc_a, cc_b, out_a, out_b, var_out, B);
+}
+
+int tfhe_hip_gate_dev_noalloc(tfhe_hip_ctx* ctx, int gate, const int32_t* ca_a, const int32_t* ca_b,
+                              const int32_t* cb_a, const int32_t* cb_b, const int32_t* cc_a,
+                              const int32_t* cc_b, int32_t* out_a, int32_t* out_b, double* var_out,
+                              size_t B) {
+  if (!ctx) return TFHE_HIP_ERR_ARG;
+  // The per-launch timing of tfhe_hip_profile_* creates events; not on this path.
+  const bool profile = ctx->profile;
+  ctx->profile = false;
+  const int rc = gate_on_device(ctx, true, gate, ca_a, ca_b, cb_a, cb_b, cc_a, cc_b, out_a, out_b, var_out, B);
+  ctx->profile = profile;
+  return rc;
 }
 
 int tfhe_hip_polymul_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, int32_t* out,

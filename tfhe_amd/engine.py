@@ -358,6 +358,18 @@ class Engine:
                                                _tp(cb_a), _tp(cb_b), _tp(cc_a), _tp(cc_b),
                                                _tp(out_a), _tp(out_b), _tp(var), B))
 
+    def gate_dev_noalloc(self, gate, ca_a, ca_b, cb_a, cb_b, out_a, out_b, cc_a=None, cc_b=None, var=None):
+        """gate_dev through the entry point that allocates nothing (fixed scratch, bounded batch)."""
+        B, n = ca_b.numel(), self.params.n
+        self._dev_sample(ca_a, ca_b, B, n, "ca")
+        self._dev_sample(cb_a, cb_b, B, n, "cb")
+        self._dev_sample(out_a, out_b, B, n, "out")
+        if cc_a is not None:
+            self._dev_sample(cc_a, cc_b, B, n, "cc")
+        self._check(self.lib.tfhe_hip_gate_dev_noalloc(self.ctx, GATE_ID[gate], _tp(ca_a), _tp(ca_b),
+                                                       _tp(cb_a), _tp(cb_b), _tp(cc_a), _tp(cc_b),
+                                                       _tp(out_a), _tp(out_b), _tp(var), B))
+
     def circuit_add_dev(self, a_a, a_b, b_a, b_b, sum_a, sum_b, carry_a, carry_b, sum_var=None,
                         carry_var=None):
         bits, count = a_b.shape
