@@ -84,25 +84,49 @@ def reference_style_keys(level, seed):
 
 
 def measured_traffic(level, batch):
-    """HBM-side bytes per blind-rotate launch from the committed PMC passes
-    (profiles/r01_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this very
-    command line, corrected as the CDNA4 guide prescribes).  Only valid for the
-    workload it was collected on; otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if level != 80 or batch != 16384 or not os.path.exists(path):
-        return None
+    """HBM-side bytes per blind-rotate launch from the committed PMC passes of this very
+    command line (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, corrected as the
+    CDNA4 guide prescribes; tools/collect_profiles.py writes the file).  Counters cannot be
+    read inside the timed run, so this is a profiled value: only valid for the workload it was
+    collected on, otherwise null."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if level != 80 or batch != 16384 or not os.path.exists(path):
+            continue
+        try:
+            return float(json.load(open(path))["traffic_bytes_per_launch"]), "profiles/" + name
+        except Exception:  # noqa: BLE001
+            continue
+    return None, None
+
+
+def host_threads():
+    """Threads for the CPU baseline: the CPUs this process may run on, capped by the share
+    the GPU box grants a one-GPU job (it exports that share as OMP_NUM_THREADS; nproc there
+    shows the whole machine)."""
     try:
-        return float(json.load(open(path))["traffic_bytes_per_launch"])
-    except Exception:  # noqa: BLE001
-        return None
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    share = os.environ.get("OMP_NUM_THREADS")
+    if share and share.isdigit() and int(share) > 0:
+        n = min(n, int(share))
+    return max(1, n)
 
 
 def cpu_baseline(level):
     """Times the CPU restatement of tfhe_bootstrap (the checker, oracle/) on the host."""
     exe = os.path.join(ROOT, "oracle", "cpu_baseline")
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("cpu_baseline.cpp", "oracle.cpp", "oracle.h")]
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(x) for x in srcs):
+        try:
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "cpu_baseline"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except Exception:  # noqa: BLE001
+            pass
     if not os.path.exists(exe):
         return None
-    cores = max(1, min(16, os.cpu_count() or 1))
+    cores = host_threads()
     per_thread = 2
     try:
         out = subprocess.run([exe, str(level), str(cores), str(per_thread)], capture_output=True,
@@ -111,10 +135,24 @@ def cpu_baseline(level):
     except Exception as e:  # noqa: BLE001
         return {"value": None, "error": repr(e)}
     return {"value": r["gates_per_sec"], "unit": "gates/s", "cores": cores, "kind": "port",
+            "per_core": r["gates_per_sec"] / cores,
             "sample": f"{r['gates']} tfhe_bootstrap calls ({per_thread} per thread, {cores} threads "
-                      f"at once) on reference-style Bit{level} keys; C++ restatement of the "
+                      f"at once = every CPU this job may use; os.cpu_count() = {os.cpu_count()}) on "
+                      f"reference-style Bit{level} keys; C++ restatement of the "
                       f"reference algorithm with a fresh FFT plan per product as in "
                       f"src/numerics.rs:235-251, not the Rust binary"}
+
+
+def oracle_check(level, K, ca_a, ca_b, cb_a, cb_b, out_a, out_b, index):
+    """One gate of the timed batch against the CPU oracle (the checker; never timed)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as orc
+    P = orc.params(level)
+    Ko = {k: np.ascontiguousarray(v) for k, v in K.items()}
+    a = (ca_a[index].cpu().numpy(), int(ca_b[index]), 0.0)
+    b = (cb_a[index].cpu().numpy(), int(cb_b[index]), 0.0)
+    wa, wb, _ = orc.gate(P, "nand", Ko, a, b, None, orc.MUL_FFT)
+    return bool((out_a[index].cpu().numpy() == wa).all() and int(out_b[index]) == wb)
 
 
 def side_workload(args):
@@ -216,6 +254,96 @@ def side_workload(args):
         dist.destroy_process_group()
 
 
+def time_nand(eng, torch, dist, dev, world, rank, level, K, B, steps, warmup, check=True):
+    """Times `steps` batches of B NAND gates on the loaded keys; returns the measurements of
+    this rank (max over ranks for the elapsed time) and checks one timed output."""
+    lv = LEVELS[level]
+    n = lv["n"]
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank + level)
+
+    def rnd(shape):
+        return torch.randint(-2**31, 2**31, shape, dtype=torch.int64, device=dev,
+                             generator=g).to(torch.int32)
+
+    ca_a, ca_b, cb_a, cb_b = rnd((B, n)), rnd((B,)), rnd((B, n)), rnd((B,))
+    out_a = torch.empty((B, n), dtype=torch.int32, device=dev)
+    out_b = torch.empty((B,), dtype=torch.int32, device=dev)
+
+    def step():
+        eng.gate_dev("nand", ca_a, ca_b, cb_a, cb_b, out_a, out_b)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    fence()
+    eng.profile_enable(True)
+    eng.profile_read()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    br_ms, br_cnt = prof["blind_rotate"]
+    ks_ms, ks_cnt = prof["keyswitch"]
+    br_avg_s = br_ms / max(br_cnt, 1) / 1e3
+    flop_launch = flop_per_iteration(lv["l"]) * lv["n"] * B
+    achieved = flop_launch / br_avg_s / 1e12 if br_avg_s > 0 else 0.0
+    traffic, traffic_from = measured_traffic(level, B)
+    res = {
+        "value": B * world * steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
+        "roofline": {"bound": "fp64_valu", "kernel": "blind_rotate_kernel",
+                     "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
+                     "traffic": traffic, "traffic_profiled_from": traffic_from,
+                     "flop_per_launch": flop_launch, "avg_launch_ms": br_avg_s * 1e3,
+                     "launches": br_cnt},
+        "kernels_ms_per_launch": {"blind_rotate": br_ms / max(br_cnt, 1),
+                                  "keyswitch": ks_ms / max(ks_cnt, 1),
+                                  "prologue": prof["prologue"][0] / max(prof["prologue"][1], 1)},
+    }
+    if check and rank == 0 and K is not None:
+        # the outputs of the last timed step: one gate against the CPU oracle
+        res["output_check"] = {"gate_index": B // 3, "matches_oracle": oracle_check(
+            level, K, ca_a, ca_b, cb_a, cb_b, out_a, out_b, B // 3)}
+    return res, (ca_a, ca_b, cb_a, cb_b, out_a, out_b)
+
+
+def latency(eng, torch, tensors, K_params_n):
+    """p50 of one NAND (B = 1), host-observed submit-to-completion: through the device-pointer
+    entry point (operands resident in HBM) and through the host-pointer entry point (what a
+    single tfhe_bootstrap-style call from the reference's API pays: staging both ways)."""
+    ca_a, ca_b, cb_a, cb_b, out_a, out_b = tensors
+    lat = []
+    for _ in range(201):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng.gate_dev("nand", ca_a[:1], ca_b[:1], cb_a[:1], cb_b[:1], out_a[:1], out_b[:1])
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t1)
+    p50_dev = sorted(lat[1:])[len(lat[1:]) // 2] * 1e3
+    ha = (ca_a[:1].cpu().numpy(), ca_b[:1].cpu().numpy())
+    hb = (cb_a[:1].cpu().numpy(), cb_b[:1].cpu().numpy())
+    lat = []
+    for _ in range(101):
+        t1 = time.perf_counter()
+        eng.gate("nand", ha, hb)
+        lat.append(time.perf_counter() - t1)
+    p50_host = sorted(lat[1:])[len(lat[1:]) // 2] * 1e3
+    return p50_dev, p50_host
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,6 +353,8 @@ def main():
     ap.add_argument("--level", type=int, default=80, choices=[80, 128])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--no-bit128", action="store_true",
+                    help="skip the Bit128 block that the default Bit80 run adds")
     ap.add_argument("--workload", default="nand", choices=["nand", "add32", "polymul"])
     ap.add_argument("--keys", default="synthetic", choices=["synthetic", "reference"],
                     help="synthetic: every key entry uniform (no stage degenerates); reference: "
@@ -249,81 +379,46 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
-    lv = LEVELS[args.level]
-    params = tfhe_amd.make_params(lv["n"], l=lv["l"], bg_bit=lv["bg_bit"])
     eng = tfhe_amd.Engine(dev.index)
     eng.use_torch_stream()
 
-    # keys: rank 0 loads and transforms, the device blobs are broadcast once
-    if rank == 0:
-        K = (synthetic_keys if args.keys == "synthetic" else reference_style_keys)(args.level, 0xC0FFEE + 3)
-        eng.load_keys(params, K["bk"], K["ks_a"], K["ks_b"], K["ks_var"])
-    if world > 1:
-        from tfhe_amd import parallel
-        parallel.replicate_keys(eng, params, dev, src=0)
-
-    B, n = args.batch, lv["n"]
-    g = torch.Generator(device=dev)
-    g.manual_seed(1234 + rank)
-
-    def rnd(shape):
-        return torch.randint(-2**31, 2**31, shape, dtype=torch.int64, device=dev,
-                             generator=g).to(torch.int32)
-
-    ca_a, ca_b, cb_a, cb_b = rnd((B, n)), rnd((B,)), rnd((B, n)), rnd((B,))
-    out_a = torch.empty((B, n), dtype=torch.int32, device=dev)
-    out_b = torch.empty((B,), dtype=torch.int32, device=dev)
-
-    def step():
-        eng.gate_dev("nand", ca_a, ca_b, cb_a, cb_b, out_a, out_b)
-
-    def fence():
-        torch.cuda.synchronize()
+    def load(level):
+        """rank 0 loads and transforms, the device blobs are broadcast once"""
+        lv = LEVELS[level]
+        params = tfhe_amd.make_params(lv["n"], l=lv["l"], bg_bit=lv["bg_bit"])
+        K = None
+        if rank == 0:
+            K = (synthetic_keys if args.keys == "synthetic" else reference_style_keys)(level, 0xC0FFEE + 3)
+            eng.load_keys(params, K["bk"], K["ks_a"], K["ks_b"], K["ks_var"])
         if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+            from tfhe_amd import parallel
+            parallel.replicate_keys(eng, params, dev, src=0)
+        return K
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    eng.profile_enable(True)
-    eng.profile_read()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = eng.profile_read()
-    eng.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # p50 latency of one gate (B = 1), rank 0 only
-    p50 = None
+    B = args.batch
+    lv = LEVELS[args.level]
+    K = load(args.level)
+    main_res, tensors = time_nand(eng, torch, dist, dev, world, rank, args.level, K, B, args.steps, args.warmup)
+    p50 = p50_host = None
     if rank == 0 and not args.no_latency:
-        lat = []
-        for _ in range(201):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            eng.gate_dev("nand", ca_a[:1], ca_b[:1], cb_a[:1], cb_b[:1], out_a[:1], out_b[:1])
-            torch.cuda.synchronize()
-            lat.append(time.perf_counter() - t1)
-        p50 = sorted(lat[1:])[len(lat[1:]) // 2] * 1e3    # host-observed: submit to completion
+        p50, p50_host = latency(eng, torch, tensors, lv["n"])
+    del tensors
+
+    # Bit128 (the crate's Parameters::default, src/lwe.rs:235-241) beside the bench's Bit80
+    bit128 = None
+    if args.level == 80 and not args.no_bit128:
+        K128 = load(128)
+        bit128, t128 = time_nand(eng, torch, dist, dev, world, rank, 128, K128, B, max(2, min(args.steps, 3)), 1)
+        del t128, K128
+        if rank == 0:
+            bit128["unit"] = "gates/s"
+            bit128["config"] = "same batch on Bit128 (n=630, N=1024, k=1, l=3, Bg=2^7, ks t=8 base=4)"
 
     if rank == 0:
-        gates = B * world * args.steps
-        value = gates / elapsed
-        br_ms, br_cnt = prof["blind_rotate"]
-        ks_ms, ks_cnt = prof["keyswitch"]
-        br_avg_s = br_ms / max(br_cnt, 1) / 1e3
-        flop_launch = flop_per_iteration(lv["l"]) * lv["n"] * B
-        achieved = flop_launch / br_avg_s / 1e12 if br_avg_s > 0 else 0.0
         res = {
             "metric": "bootstrapped NAND gates/sec (node, default params)",
-            "value": value, "unit": "gates/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "value": main_res["value"], "unit": "gates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"batched bootstrapped NAND, {B} gates per GPU per step, "
@@ -332,15 +427,11 @@ def main():
                        "batch_per_gpu": B, "security_level": args.level,
                        "parallelism": f"batch sharded over {world} GPU(s), keys replicated"},
             "p50_single_gate_latency_ms": p50,
-            "roofline": {"bound": "fp64_valu", "kernel": "blind_rotate_kernel",
-                         "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
-                         "traffic": measured_traffic(args.level, B),
-                         "flop_per_launch": flop_launch, "avg_launch_ms": br_avg_s * 1e3,
-                         "launches": br_cnt},
-            "kernels_ms_per_launch": {"blind_rotate": br_ms / max(br_cnt, 1),
-                                      "keyswitch": ks_ms / max(ks_cnt, 1),
-                                      "prologue": prof["prologue"][0] / max(prof["prologue"][1], 1)},
+            "p50_single_gate_latency_host_pointers_ms": p50_host,
+            "roofline": main_res["roofline"],
+            "kernels_ms_per_launch": main_res["kernels_ms_per_launch"],
+            "output_check": main_res.get("output_check"),
+            "bit128": bit128,
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.level)

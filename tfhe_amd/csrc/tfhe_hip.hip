@@ -64,7 +64,21 @@ struct StampCtx {
 #define TFHE_K1_DEPTH 4
 #endif
 
+// Where the accumulator of the blind rotation lives between uses: parked in
+// accumulation registers by hand (0) or left to the register allocator (1).
+#ifndef TFHE_ACC_VGPR
+#define TFHE_ACC_VGPR 0
+#endif
+
 namespace {
+
+#if TFHE_ACC_VGPR
+__device__ __forceinline__ unsigned acc_put(unsigned v) { return v; }
+__device__ __forceinline__ unsigned acc_get(unsigned a) { return a; }
+#else
+__device__ __forceinline__ unsigned acc_put(unsigned v) { return wfft::agpr_put(v); }
+__device__ __forceinline__ unsigned acc_get(unsigned a) { return wfft::agpr_get(a); }
+#endif
 
 constexpr int kN = 1024;
 constexpr int kWavesPerBlock = 4;
@@ -256,7 +270,7 @@ __device__ __forceinline__ void extprod_accumulate(unsigned (&acc_a)[32], const 
   auto accumulate = [&](auto rc, double v) WFFT_INLINE {
     constexpr int r = decltype(rc)::value;
     margin.track(v);
-    acc_a[r] = wfft::agpr_put((unsigned)wadd((int32_t)wfft::agpr_get(acc_a[r]), wfft::round_sat_i32(v)));
+    acc_a[r] = acc_put((unsigned)wadd((int32_t)acc_get(acc_a[r]), wfft::round_sat_i32(v)));
   };
 #pragma unroll 1
   for (int p = 0; p < L; p++)
@@ -269,6 +283,10 @@ __device__ __forceinline__ void extprod_accumulate(unsigned (&acc_a)[32], const 
 // h, coefficient q + 32 r); prev and t (XORed with mask, see tt_mask) live in
 // the wavefront's LDS share; the
 // sum prev + acc is staged through the exchange area for the rotation.
+// GENERAL: abar is any i32 (caller-supplied powers of the blind-rotate hook);
+// otherwise abar is in [-N, N-1], all that decode_message(x, 2N) produces
+// (src/numerics.rs:126-130), and cycle is set exactly when abar == -N.
+template <bool GENERAL>
 __device__ __forceinline__ void rotate_diff(const unsigned (&acc_a)[32], int abar, char* wave_lds,
                                             int lane, uint32_t mask) {
   const int h = lane >> 5, q = lane & 31;
@@ -283,7 +301,7 @@ __device__ __forceinline__ void rotate_diff(const unsigned (&acc_a)[32], int aba
   wfft::wave_lds_fence();
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
-    const int32_t a = (int32_t)wfft::agpr_get(acc_a[r]);
+    const int32_t a = (int32_t)acc_get(acc_a[r]);
     S[q + 32 * r] = wadd(v[r], a);
     pv[32 * r] = a;
   });
@@ -292,23 +310,37 @@ __device__ __forceinline__ void rotate_diff(const unsigned (&acc_a)[32], int aba
   // pw = abar % N (both truncating, as in Rust), coefficient n comes from
   // (n - pw) mod N; it is negated when it wraps (pw > 0 and n < pw) unless cycle
   // is set, and negated everywhere else exactly when cycle is set.
-  const MonomialPower mp = monomial_power(abar);
-  const int base = q - mp.pw;
-  static_for<0, 32>([&](auto ic) WFFT_INLINE {
-    constexpr int r = decltype(ic)::value;
-    v[r] = S[(base + 32 * r) & (kN - 1)];
-  });
-  wfft::wave_lds_fence();
-  auto emit = [&](auto cyc) WFFT_INLINE {
+  if constexpr (GENERAL) {
+    const MonomialPower mp = monomial_power(abar);
+    const int base = q - mp.pw;
     static_for<0, 32>([&](auto ic) WFFT_INLINE {
       constexpr int r = decltype(ic)::value;
-      const bool neg = (base < -32 * r) != decltype(cyc)::value;
-      const int32_t x = neg ? wneg(v[r]) : v[r];
-      tt[64 * r] = (int32_t)((uint32_t)wsub(x, (int32_t)wfft::agpr_get(acc_a[r])) ^ mask);
+      v[r] = S[(base + 32 * r) & (kN - 1)];
     });
-  };
-  if (mp.cycle) emit(std::true_type{});      // wave-uniform; rare on the bootstrap path (abar = -N)
-  else emit(std::false_type{});
+    wfft::wave_lds_fence();
+    static_for<0, 32>([&](auto ic) WFFT_INLINE {
+      constexpr int r = decltype(ic)::value;
+      const bool neg = (base < -32 * r) != mp.cycle;
+      const int32_t x = neg ? wneg(v[r]) : v[r];
+      tt[64 * r] = (int32_t)((uint32_t)wsub(x, (int32_t)acc_get(acc_a[r])) ^ mask);
+    });
+  } else {
+    // pw = abar and cycle = 0 except for abar = -N (pw = 0, cycle = 1: all negated);
+    // `wrap` folds both into one comparison per coefficient.
+    const int base = q - abar;
+    const int wrap = abar > 0 ? base : (abar == -kN ? -(1 << 20) : (1 << 20));
+    static_for<0, 32>([&](auto ic) WFFT_INLINE {
+      constexpr int r = decltype(ic)::value;
+      v[r] = S[(base + 32 * r) & (kN - 1)];
+    });
+    wfft::wave_lds_fence();
+    static_for<0, 32>([&](auto ic) WFFT_INLINE {
+      constexpr int r = decltype(ic)::value;
+      const bool neg = wrap < -32 * r;
+      const int32_t x = neg ? wneg(v[r]) : v[r];
+      tt[64 * r] = (int32_t)((uint32_t)wsub(x, (int32_t)acc_get(acc_a[r])) ^ mask);
+    });
+  }
   wfft::wave_lds_fence();
 }
 
@@ -357,7 +389,7 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
   wfft::wave_lds_fence();
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
-    acc_a[r] = wfft::agpr_put(
+    acc_a[r] = acc_put(
         HOOK ? (unsigned)args.acc_io[((size_t)b * 3 + h) * kN + q + 32 * r] : 0u);
     // the previous accumulator starts at zero, bootstrapping.rs:116-117
     reinterpret_cast<int32_t*>(wave_tiles + kPrevOff)[h * kN + q + 32 * r] = 0;
@@ -375,7 +407,7 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
     int ln = lane;
     asm volatile("" : "+v"(ln));
     TFHE_STAMP(st, 8);
-    rotate_diff(acc_a, abar, wave_tiles, ln, tt_mask<L, BGBIT>());   // also prev <- acc
+    rotate_diff<HOOK>(acc_a, abar, wave_tiles, ln, tt_mask<L, BGBIT>());   // also prev <- acc
     TFHE_STAMP(st, 0);
     extprod_accumulate<L, BGBIT>(acc_a, args.bkfft + (size_t)i * L * 2 * 2048, wave_tiles, tE, tw, ln,
                                  st);
@@ -388,7 +420,7 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
   if (HOOK) {
     static_for<0, 32>([&](auto ic) WFFT_INLINE {
       constexpr int r = decltype(ic)::value;
-      args.acc_io[((size_t)b * 3 + h) * kN + q + 32 * r] = (int32_t)wfft::agpr_get(acc_a[r]);
+      args.acc_io[((size_t)b * 3 + h) * kN + q + 32 * r] = (int32_t)acc_get(acc_a[r]);
     });
   } else {
     // extract_lwe, src/tlwe.rs:159-180 (k = 1): a[0] = acc0[0], a[j] = -acc0[N-j].
@@ -397,7 +429,7 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
       static_for<0, 32>([&](auto ic) WFFT_INLINE {
         constexpr int r = decltype(ic)::value;
         const int t = q + 32 * r;
-        const int32_t v = (int32_t)wfft::agpr_get(acc_a[r]);
+        const int32_t v = (int32_t)acc_get(acc_a[r]);
         if (t == 0) oa[0] = v;
         else oa[kN - t] = wneg(v);
       });
@@ -597,7 +629,7 @@ __global__ __launch_bounds__(kBlock, 1) void extprod_kernel(const int32_t* __res
     constexpr int r = decltype(ic)::value;
     reinterpret_cast<int32_t*>(wave_tiles + kTtOff)[2 * (q + 32 * r) + h] =
         (int32_t)((uint32_t)t[((size_t)b * 3 + h) * kN + q + 32 * r] ^ tt_mask<L, BGBIT>());
-    acc_a[r] = wfft::agpr_put(0u);
+    acc_a[r] = acc_put(0u);
   });
   StampCtx st;
   if constexpr (MARGIN) {
@@ -616,7 +648,7 @@ __global__ __launch_bounds__(kBlock, 1) void extprod_kernel(const int32_t* __res
   }
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
-    out[((size_t)b * 3 + h) * kN + q + 32 * r] = (int32_t)wfft::agpr_get(acc_a[r]);
+    out[((size_t)b * 3 + h) * kN + q + 32 * r] = (int32_t)acc_get(acc_a[r]);
     if (h == 0) out[((size_t)b * 3 + 2) * kN + q + 32 * r] = 0;     // tgsw.rs:236-244
   });
 }

@@ -1,43 +1,84 @@
-"""Copies the summaries of one measurement pass into profiles/ (kernel stats, bench lines, PMC sums
-per kernel, traffic).  The pass directory holds bench80.json, bench128.json, bench80_refkeys.json,
-add32.json, polymul.json (bench.py lines), prof/ (rocprofv3 --kernel-trace --stats --output-format csv),
-pmc_fetch/, pmc_write/, pmc_sq/ (rocprofv3 --pmc ... --kernel-trace --output-format csv of
-`bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-latency`) and bench_prof.log.
-usage: python tools/collect_profiles.py gpurun_out/<pass>"""
-import collections, csv, glob, json, shutil, sys
-R, P = sys.argv[1], "profiles"
-names = {"bench80": "r01_bench_bit80", "bench128": "r01_bench_bit128", "bench80_refkeys": "r01_bench_bit80_reference_style_keys",
-         "add32": "r01_bench_add32", "polymul": "r01_bench_polymul"}
-for f, o in names.items():
+"""Summaries of one measurement pass (tools/measure.sh) for profiles/.
+
+  python tools/collect_profiles.py <pass dir> --sums-only   (on the GPU box) reduces every
+      counter CSV of the pass to per-kernel sums, <pass dir>/pmc_sums.json
+  python tools/collect_profiles.py <pass dir> <prefix>      copies bench lines, kernel statistics,
+      counter sums and the derived HBM traffic into profiles/<prefix>_*
+Traffic: FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of wide
+reads, so it is doubled (the CDNA4 guide's correction).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+R = sys.argv[1]
+
+
+def kernel_key(name):
+    for k in ("blind_rotate_split_kernel", "blind_rotate_kernel", "keyswitch_tile_kernel", "keyswitch_kernel",
+              "prologue_kernel", "polymul_kernel", "bk_fft_kernel"):
+        if k in name:
+            return k
+    return None
+
+
+if sys.argv[2] == "--sums-only":
+    out = {}
+    for d in sorted(glob.glob(R + "/pmc_*")):
+        files = glob.glob(d + "/vm/*_counter_collection.csv") + glob.glob(d + "/**/*_counter_collection.csv", recursive=True)
+        if not os.path.isdir(d) or not files:
+            continue
+        agg = collections.defaultdict(float)
+        disp = collections.defaultdict(set)
+        for row in csv.DictReader(open(files[0])):
+            k = kernel_key(row["Kernel_Name"])
+            if k is None:
+                continue
+            agg[(k, row["Counter_Name"])] += float(row["Counter_Value"])
+            disp[(k, row["Counter_Name"])].add(row.get("Dispatch_Id"))
+        per = {}
+        for (k, c), v in agg.items():
+            per.setdefault(k, {})[c] = {"sum": v, "dispatches": len(disp[(k, c)])}
+        out[os.path.basename(d)] = per
+    json.dump(out, open(R + "/pmc_sums.json", "w"), indent=1)
+    sys.exit(0)
+
+PRE, P = sys.argv[2], "profiles"
+for f in ("bench80", "bench128", "bench80_refkeys", "add32", "polymul"):
     d = json.load(open(f"{R}/{f}.json"))
     print(f, round(d["value"], 1), d.get("p50_single_gate_latency_ms"), d.get("roofline", {}).get("frac"),
           d.get("kernels_ms_per_launch"), (d.get("cpu_baseline") or {}).get("value"))
-    shutil.copy(f"{R}/{f}.json", f"{P}/{o}.json")
-ks = glob.glob(R + "/prof/vm/*_kernel_stats.csv")[0]
-for i, row in enumerate(csv.DictReader(open(ks))):
-    if i < 3: print(row["Name"][:60], row["Calls"], row["AverageNs"], row["Percentage"])
-shutil.copy(ks, P + "/r01_bench_kernel_stats.csv")
-shutil.copy(R + "/bench_prof.log", P + "/r01_bench_under_rocprof.log")
-summ = {}
-for kind in ("fetch", "write", "sq"):
-    f = glob.glob(f"{R}/pmc_{kind}/vm/*_counter_collection.csv")[0]
-    agg = collections.defaultdict(float); cnt = collections.Counter()
-    for row in csv.DictReader(open(f)):
-        kn = row["Kernel_Name"]
-        k = ("blind_rotate_kernel<2,10,false>" if "blind_rotate" in kn else "keyswitch_tile_kernel<8>" if "keyswitch" in kn
-             else "prologue_kernel" if "prologue" in kn else None)
-        if k is None: continue
-        agg[(k, row["Counter_Name"])] += float(row["Counter_Value"]); cnt[(k, row["Counter_Name"])] += 1
-    out = {}
-    for (k, c), v in agg.items(): out.setdefault(k, {})[c] = {"sum": v, "dispatches": cnt[(k, c)]}
-    summ[kind] = out
-    json.dump({"command": "rocprofv3 --pmc <counters> --kernel-trace --output-format csv -- python3 bench.py --steps 1 "
-                          "--warmup 0 --no-cpu-baseline --no-latency", "per_kernel": out},
-              open(f"{P}/r01_pmc_{kind}_summary.json", "w"), indent=1)
-br = "blind_rotate_kernel<2,10,false>"
-f, w = summ["fetch"][br]["FETCH_SIZE"]["sum"], summ["write"][br]["WRITE_SIZE"]["sum"]
-traffic = 2 * f * 1024 + w * 1024
-json.dump({"kernel": br, "workload": "bench.py default: 16384 NAND gates, Bit80", "FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB": w,
-           "correction": "FETCH_SIZE x2 on gfx950, units KiB", "traffic_bytes_per_launch": traffic},
-          open(P + "/r01_traffic.json", "w"), indent=1)
-print("traffic GB", traffic / 1e9, {k: v["sum"] for k, v in summ["sq"][br].items()})
+    shutil.copy(f"{R}/{f}.json", f"{P}/{PRE}_{f}.json")
+for sub, o in (("prof", "bench_kernel_stats"), ("prof_polymul", "polymul_kernel_stats")):
+    ks = glob.glob(f"{R}/{sub}/**/*_kernel_stats.csv", recursive=True)[0]
+    for i, row in enumerate(csv.DictReader(open(ks))):
+        if i < 3:
+            print(row["Name"][:60], row["Calls"], row["AverageNs"], row["Percentage"])
+    shutil.copy(ks, f"{P}/{PRE}_{o}.csv")
+shutil.copy(R + "/bench_prof.log", f"{P}/{PRE}_bench_under_rocprof.log")
+sums = json.load(open(R + "/pmc_sums.json"))
+json.dump({"commands": "see tools/measure.sh: one rocprofv3 --pmc run per counter group over "
+                       "`bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-latency --no-bit128` "
+                       "(and `--workload polymul --steps 1 --warmup 0`)", "per_pass": sums},
+          open(f"{P}/{PRE}_pmc_sums.json", "w"), indent=1)
+
+
+def traffic(fetch_pass, write_pass, kernel):
+    f = sums[fetch_pass][kernel]["FETCH_SIZE"]
+    w = sums[write_pass][kernel]["WRITE_SIZE"]
+    return {"kernel": kernel, "FETCH_SIZE_KiB_raw": f["sum"], "WRITE_SIZE_KiB": w["sum"], "dispatches": f["dispatches"],
+            "correction": "FETCH_SIZE x2 on gfx950, units KiB",
+            "traffic_bytes_per_launch": (2 * f["sum"] + w["sum"]) * 1024 / f["dispatches"]}
+
+
+t = traffic("pmc_fetch", "pmc_write", "blind_rotate_kernel")
+t["workload"] = "bench.py default: 16384 NAND gates, Bit80"
+json.dump(t, open(f"{P}/{PRE}_traffic.json", "w"), indent=1)
+tp = traffic("pmc_fetch_polymul", "pmc_write_polymul", "polymul_kernel")
+tp["workload"] = "bench.py --workload polymul: 65536 products"
+json.dump(tp, open(f"{P}/{PRE}_traffic_polymul.json", "w"), indent=1)
+print("traffic GB per launch: blind rotate", t["traffic_bytes_per_launch"] / 1e9, "polymul", tp["traffic_bytes_per_launch"] / 1e9)

@@ -1,0 +1,30 @@
+#!/bin/bash
+# One measurement pass on the GPU box: bench lines, rocprofv3 kernel statistics and the PMC
+# passes (each counter group in a run of its own, no trace domains beside --kernel-trace).
+# usage: tools/measure.sh <pass-name>     results under gpurun_out/<pass-name>/
+# tools/collect_profiles.py copies the summaries into profiles/.
+set -o pipefail
+P=$PWD/gpurun_out/$1
+mkdir -p $P
+export TMPDIR=/tmp
+T="timeout -k 10"
+Q="--no-cpu-baseline --no-latency --no-bit128"
+$T 400 python bench.py --steps 10 > $P/bench80.json 2> $P/bench80.err || exit 1
+$T 200 python bench.py --level 128 --steps 5 > $P/bench128.json 2>> $P/bench80.err || exit 1
+$T 200 python bench.py --keys reference --steps 5 $Q > $P/bench80_refkeys.json 2>> $P/bench80.err || exit 1
+$T 300 python bench.py --workload add32 --steps 1 --warmup 0 > $P/add32.json 2>> $P/bench80.err || exit 1
+$T 200 python bench.py --workload polymul --steps 50 --warmup 5 > $P/polymul.json 2>> $P/bench80.err || exit 1
+$T 300 rocprofv3 --kernel-trace --stats -d $P/prof -o vm --output-format csv -- python3 bench.py --steps 3 $Q > $P/bench_prof.log 2>&1 || exit 1
+$T 300 rocprofv3 --kernel-trace --stats -d $P/prof_polymul -o vm --output-format csv -- python3 bench.py --workload polymul --steps 20 --warmup 2 > $P/polymul_prof.log 2>&1 || exit 1
+ONE="python3 bench.py --steps 1 --warmup 0 $Q"
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $P/pmc_fetch -o vm --output-format csv -- $ONE > $P/pmc_fetch.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $P/pmc_write -o vm --output-format csv -- $ONE > $P/pmc_write.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAVES --kernel-trace -d $P/pmc_sq -o vm --output-format csv -- $ONE > $P/pmc_sq.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY --kernel-trace -d $P/pmc_act -o vm --output-format csv -- $ONE > $P/pmc_act.log 2>&1 || exit 1
+PM="python3 bench.py --workload polymul --steps 1 --warmup 0"
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $P/pmc_fetch_polymul -o vm --output-format csv -- $PM > $P/pmc_fetch_polymul.log 2>&1 || exit 1
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $P/pmc_write_polymul -o vm --output-format csv -- $PM > $P/pmc_write_polymul.log 2>&1 || exit 1
+# the CSVs of the counter passes are large; keep per-kernel sums only
+python3 tools/collect_profiles.py $P --sums-only
+rm -rf $P/pmc_*/vm
+echo measure done
