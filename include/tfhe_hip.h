@@ -122,6 +122,37 @@ int tfhe_hip_profile_read(tfhe_hip_ctx* ctx, double ms_sum[3], int launches[3]);
 int tfhe_hip_load_keys(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, const int32_t* bk,
                        const int32_t* ks_a, const int32_t* ks_b, const double* ks_var);
 
+/* generate_keys on the GPU: LweKey::generate (src/lwe.rs:294-309),
+ * TGswKey::generate (src/tgsw.rs:81-89, src/tlwe.rs:43-64) and
+ * LweBootstrappingKey::create (src/lwe.rs:474-493: LweKey::extract,
+ * LweKeySwitchKey::create :530-558 with its recentred Gaussian noises, and one
+ * TGswKey::encrypt per key bit, src/tgsw.rs:91-176, src/tlwe.rs:112-134), with the
+ * key structure the reference's code produces (only decomposition row 0 of a
+ * TGSW sample is encrypted; its body keeps one Gaussian coefficient among its
+ * first N; the gadget adds key bit * l to coefficient 0 of every polynomial of row
+ * 0; key-switch samples of digit 0 are zero).  ks_stdev / bk_stdev are
+ * alpha_min of the in/out and of the TLWE parameters (Parameters::with,
+ * src/lwe.rs:179-232).
+ * The reference draws from rand's thread_rng (an OS-seeded ChaCha generator that
+ * callers cannot seed); here every random value is a documented function of
+ * `seed` (32 bytes = the ChaCha20 key, RFC 8439 block function; the addressing
+ * is described at the kernels), so a seed reproduces its keys.  Use a seed from
+ * the operating system's entropy source for real keys.
+ * On return the context holds the keys exactly as after tfhe_hip_load_keys (on a
+ * multi-GPU context: generated on devices[0], then replicated) and the SECRET
+ * keys are in lwe_key [n] and tlwe_key [(k+1)][N] (may be NULL).  bk_out, ks_a_out,
+ * ks_b_out, ks_var_out (each may be NULL) receive the cloud key in the layouts
+ * of tfhe_hip_load_keys, e.g. for tfhe_hip_key_file_pack. */
+int tfhe_hip_generate_keys(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, double ks_stdev,
+                           double bk_stdev, const uint8_t seed[32], int32_t* lwe_key,
+                           int32_t* tlwe_key, int32_t* bk_out, int32_t* ks_a_out, int32_t* ks_b_out,
+                           double* ks_var_out);
+/* The keystream behind tfhe_hip_generate_keys (test hook): out [nblocks][16] =
+ * ChaCha20 blocks first_block .. of (seed, purpose, stream), where the block's
+ * state words 12..15 are block counter, purpose, stream low, stream high. */
+int tfhe_hip_keygen_stream(tfhe_hip_ctx* ctx, const uint8_t seed[32], uint32_t purpose,
+                           uint64_t stream, uint32_t first_block, uint32_t* out, size_t nblocks);
+
 /* The key file: one flat little-endian image of the key material above, so that
  * keys are generated once and loaded from disk (the reference derives
  * Serialize/Deserialize for CloudKey, LweBootstrappingKey and LweKeySwitchKey,

@@ -76,6 +76,28 @@ extern "C" {
         ks_b: *const i32,
         ks_var: *const f64,
     ) -> c_int;
+    pub fn tfhe_hip_generate_keys(
+        ctx: *mut TfheHipCtx,
+        params: *const TfheHipParams,
+        ks_stdev: f64,
+        bk_stdev: f64,
+        seed: *const u8,
+        lwe_key: *mut i32,
+        tlwe_key: *mut i32,
+        bk_out: *mut i32,
+        ks_a_out: *mut i32,
+        ks_b_out: *mut i32,
+        ks_var_out: *mut f64,
+    ) -> c_int;
+    pub fn tfhe_hip_keygen_stream(
+        ctx: *mut TfheHipCtx,
+        seed: *const u8,
+        purpose: u32,
+        stream: u64,
+        first_block: u32,
+        out: *mut u32,
+        nblocks: usize,
+    ) -> c_int;
     pub fn tfhe_hip_key_file_size(
         params: *const TfheHipParams,
         has_ks_var: c_int,

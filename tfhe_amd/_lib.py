@@ -27,6 +27,7 @@ SYMBOLS = [
     "tfhe_hip_samples_not", "tfhe_hip_samples_constant",
     "tfhe_hip_polymul_margin", "tfhe_hip_polymul_margin_dev", "tfhe_hip_extprod_margin",
     "tfhe_hip_extprod_dev", "tfhe_hip_blind_rotate_dev", "tfhe_hip_gate_dev_noalloc",
+    "tfhe_hip_generate_keys", "tfhe_hip_keygen_stream",
 ]
 NO_INT_RESULT = ("tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_samples_free", "tfhe_hip_samples_count")
 
@@ -87,6 +88,8 @@ def load():
     lib.tfhe_hip_key_file_size.argtypes = [PP, C.c_int, C.POINTER(sz)]
     lib.tfhe_hip_key_file_pack.argtypes = [PP, i32p, i32p, i32p, f64p, vp, sz]
     lib.tfhe_hip_load_keys_blob.argtypes = [vp, vp, sz]
+    lib.tfhe_hip_generate_keys.argtypes = [vp, PP, C.c_double, C.c_double, vp, i32p, i32p, i32p, i32p, i32p, f64p]
+    lib.tfhe_hip_keygen_stream.argtypes = [vp, vp, C.c_uint32, C.c_uint64, C.c_uint32, vp, sz]
     lib.tfhe_hip_not_dev.argtypes = [vp, i32p, i32p, f64p, i32p, i32p, f64p, sz]
     lib.tfhe_hip_constant_dev.argtypes = [vp, C.c_int, i32p, i32p, f64p, sz]
     lib.tfhe_hip_samples_alloc.argtypes = [vp, sz, C.POINTER(vp)]

@@ -72,6 +72,9 @@ int need_keys(tfhe_hip_ctx* ctx);
 int load_keys_multi(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, const int32_t* bk,
                     const int32_t* ks_a, const int32_t* ks_b, const double* ks_var);
 
+// keys present on shards[0]: gives every other shard a copy (host_api.cpp)
+int replicate_keys_multi(tfhe_hip_ctx* ctx, const tfhe_hip_params* params);
+
 }  // namespace tfhe_detail
 
 #define HIP_TRY(ctx, expr)                                                           \

@@ -844,9 +844,15 @@ bool rccl_broadcast_keys(const std::vector<tfhe_hip_ctx*>& leaders) {
 int tfhe_detail::load_keys_multi(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, const int32_t* bk,
                                  const int32_t* ks_a, const int32_t* ks_b, const double* ks_var) {
   ctx->have_keys = false;
-  std::vector<tfhe_hip_ctx*>& sh = ctx->shards;
   // transform once, on the first device
-  if (int rc = tfhe_hip_load_keys(sh[0], params, bk, ks_a, ks_b, ks_var)) return fail(ctx, rc, sh[0]->err);
+  if (int rc = tfhe_hip_load_keys(ctx->shards[0], params, bk, ks_a, ks_b, ks_var))
+    return fail(ctx, rc, ctx->shards[0]->err);
+  return replicate_keys_multi(ctx, params);
+}
+
+int tfhe_detail::replicate_keys_multi(tfhe_hip_ctx* ctx, const tfhe_hip_params* params) {
+  ctx->have_keys = false;
+  std::vector<tfhe_hip_ctx*>& sh = ctx->shards;
   // leaders: the first context of every distinct GPU
   std::vector<tfhe_hip_ctx*> leaders;
   std::vector<int> leader_of(sh.size(), 0);

@@ -1072,6 +1072,225 @@ __global__ void ks_var_zero_kernel(double* __restrict__ var, size_t rows) {
   if (i < rows) var[i] = 0.0;
 }
 
+// ---------------------------------------------------------------------------
+// Key generation (src/lwe.rs:294-309, 474-493, 530-558; src/tgsw.rs:81-176;
+// src/tlwe.rs:43-64, 112-134).  Randomness is the ChaCha20 keystream (RFC 8439
+// block function; the reference draws from rand 0.7's thread_rng, a ChaCha
+// generator seeded by the OS, which cannot be seeded by the caller), addressed
+// so that every value is a pure function of (seed, purpose, stream, position):
+//   state[4..11] = seed, state[12] = block counter,
+//   state[13] = purpose, state[14..15] = stream (low, high word).
+// ---------------------------------------------------------------------------
+enum : uint32_t {
+  kRngSecretLwe = 1,   // stream 0: word x, top bit = key bit x
+  kRngSecretTlwe = 2,  // stream 0: word u*N + x, top bit = bit x of key polynomial u
+  kRngKsNoise = 3,     // stream 0: words 4 idx .. 4 idx + 3 -> normal number idx
+  kRngKsMask = 4,      // stream = row ((i*t + j)*base + h): word x = mask coefficient x
+  kRngBkMask = 5,      // stream = i*(k+1) + col: word x = coefficient x of the mask polynomial
+  kRngBkNoise = 6      // stream = i*(k+1) + col: words 0..3 -> the one Gaussian that is read
+};
+
+struct ChaChaKey {
+  uint32_t w[8];
+};
+
+__host__ __device__ inline uint32_t rotl32(uint32_t v, int c) { return (v << c) | (v >> (32 - c)); }
+
+__host__ __device__ inline void chacha20_block(const ChaChaKey& key, uint32_t counter, uint32_t purpose,
+                                               uint64_t stream, uint32_t (&out)[16]) {
+  uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
+                     key.w[0], key.w[1], key.w[2], key.w[3], key.w[4], key.w[5], key.w[6], key.w[7],
+                     counter, purpose, (uint32_t)stream, (uint32_t)(stream >> 32)};
+  uint32_t x[16];
+  for (int i = 0; i < 16; i++) x[i] = in[i];
+#define TFHE_QR(a, b, c, d)                                        \
+  x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 16);                    \
+  x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 12);                    \
+  x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 8);                     \
+  x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 7);
+  for (int r = 0; r < 10; r++) {
+    TFHE_QR(0, 4, 8, 12) TFHE_QR(1, 5, 9, 13) TFHE_QR(2, 6, 10, 14) TFHE_QR(3, 7, 11, 15)
+    TFHE_QR(0, 5, 10, 15) TFHE_QR(1, 6, 11, 12) TFHE_QR(2, 7, 8, 13) TFHE_QR(3, 4, 9, 14)
+  }
+#undef TFHE_QR
+  for (int i = 0; i < 16; i++) out[i] = x[i] + in[i];
+}
+
+// One word of a stream (computes its whole block; for sparse reads).
+__device__ inline uint32_t chacha20_word(const ChaChaKey& key, uint32_t purpose, uint64_t stream, uint32_t word) {
+  uint32_t blk[16];
+  chacha20_block(key, word >> 4, purpose, stream, blk);
+  return blk[word & 15];
+}
+
+// Standard normal from four keystream words (Box-Muller on two 53-bit uniforms,
+// the first in (0, 1]).  rand_distr::Normal (src/numerics.rs:45-47) samples the same
+// distribution with another algorithm.
+__device__ inline double normal_from_words(const uint32_t* w) {
+  const uint64_t a = ((uint64_t)w[1] << 32 | w[0]) >> 11, b = ((uint64_t)w[3] << 32 | w[2]) >> 11;
+  const double u1 = ((double)a + 1.0) * (1.0 / 9007199254740992.0);
+  const double u2 = (double)b * (1.0 / 9007199254740992.0);
+  return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+}
+
+// f64_to_torus_32, src/numerics.rs:56-58: trunc(d * 2^32) as i32, a saturating cast
+// (v_cvt_i32_f64 truncates, saturates and maps NaN to 0, as Rust's `as`).
+__device__ inline int32_t f64_to_torus32(double d) {
+  const double x = d * 4294967296.0;
+  int32_t i;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(i) : "v"(x));
+  return i;
+}
+
+// Raw keystream words (test hook): out[b*16 + e] = word e of block first_block + b.
+__global__ void keygen_stream_kernel(ChaChaKey key, uint32_t purpose, uint64_t stream, uint32_t first_block,
+                                     uint32_t* __restrict__ out, size_t nblocks) {
+  const size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nblocks) return;
+  uint32_t blk[16];
+  chacha20_block(key, first_block + (uint32_t)b, purpose, stream, blk);
+  for (int e = 0; e < 16; e++) out[b * 16 + e] = blk[e];
+}
+
+// LweKey::generate (src/lwe.rs:294-309) and TLweKey::generate (src/tlwe.rs:43-64): binary keys.
+__global__ void keygen_secret_kernel(ChaChaKey key, int n, int tlwe_count, int32_t* __restrict__ lwe_key,
+                                     int32_t* __restrict__ tlwe_key) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;        // one keystream block = 16 key bits
+  const int nb_lwe = (n + 15) / 16, nb_tlwe = (tlwe_count + 15) / 16;
+  if (b >= nb_lwe + nb_tlwe) return;
+  const bool is_lwe = b < nb_lwe;
+  const int blk_index = is_lwe ? b : b - nb_lwe;
+  uint32_t blk[16];
+  chacha20_block(key, (uint32_t)blk_index, is_lwe ? kRngSecretLwe : kRngSecretTlwe, 0, blk);
+  int32_t* dst = is_lwe ? lwe_key : tlwe_key;
+  const int count = is_lwe ? n : tlwe_count;
+  for (int e = 0; e < 16; e++) {
+    const int x = blk_index * 16 + e;
+    if (x < count) dst[x] = (int32_t)(blk[e] >> 31);
+  }
+}
+
+// The Gaussian noises of LweKeySwitchKey::create (src/lwe.rs:536-541), before recentring,
+// and their sum in fixed order per workgroup (partial[blockIdx.x]).
+__global__ __launch_bounds__(256) void keygen_ks_noise_kernel(ChaChaKey key, double alpha, int size_ks,
+                                                              double* __restrict__ noise,
+                                                              double* __restrict__ partial) {
+  __shared__ double red[256];
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  double v = 0.0;
+  if (idx < size_ks) {
+    uint32_t blk[16];
+    chacha20_block(key, (uint32_t)(idx >> 2), kRngKsNoise, 0, blk);
+    v = alpha * normal_from_words(blk + 4 * (idx & 3));
+    noise[idx] = v;
+  }
+  red[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// error = sum / size_ks (src/lwe.rs:539), partial sums added in index order.
+__global__ void keygen_ks_mean_kernel(const double* __restrict__ partial, int count, int size_ks,
+                                      double* __restrict__ mean) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double sum = 0.0;
+    for (int i = 0; i < count; i++) sum += partial[i];
+    *mean = sum / (double)size_ks;
+  }
+}
+
+// LweKeySwitchKey::create (src/lwe.rs:543-557): one workgroup per sample ks[i][j][h].
+// h = 0 stays the all-zero trivial sample; h >= 1 is
+// encrypt_with_external_noise(message = key'[i] * h * 2^(32 - (j+1) base_bit), noise - error)
+// (src/lwe.rs:334-358): uniform mask, b = message + f64_to_torus32(noise) + <a, s>.
+__global__ __launch_bounds__(256) void keygen_ks_kernel(ChaChaKey key, int n, int t, int base_bit,
+                                                        double alpha, const int32_t* __restrict__ lwe_key,
+                                                        const int32_t* __restrict__ extracted_key,
+                                                        const double* __restrict__ noise,
+                                                        const double* __restrict__ mean,
+                                                        int32_t* __restrict__ ks_a, int32_t* __restrict__ ks_b,
+                                                        double* __restrict__ ks_var) {
+  __shared__ uint32_t red[256];
+  const int base = 1 << base_bit;
+  const size_t row = blockIdx.x;
+  const int h = (int)(row % base), j = (int)((row / base) % t), i = (int)(row / ((size_t)base * t));
+  int32_t* a_out = ks_a + row * n;
+  uint32_t dot = 0;
+  for (int b0 = threadIdx.x; b0 * 16 < n; b0 += blockDim.x) {
+    uint32_t blk[16] = {0};
+    if (h != 0) chacha20_block(key, (uint32_t)b0, kRngKsMask, row, blk);
+    for (int e = 0; e < 16; e++) {
+      const int x = b0 * 16 + e;
+      if (x < n) {
+        a_out[x] = (int32_t)blk[e];
+        dot += blk[e] * (uint32_t)lwe_key[x];
+      }
+    }
+  }
+  red[threadIdx.x] = dot;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (h == 0) {
+      ks_b[row] = 0;
+      ks_var[row] = 0.0;
+    } else {
+      const int index = (i * t + j) * (base - 1) + (h - 1);              // src/lwe.rs:545-556
+      const uint32_t message = (uint32_t)(extracted_key[i] * h) * (1u << (32 - (j + 1) * base_bit));
+      const int32_t b = wadd((int32_t)message, f64_to_torus32(noise[index] - *mean));
+      ks_b[row] = wadd(b, (int32_t)red[0]);
+      ks_var[row] = alpha * alpha;
+    }
+  }
+}
+
+// bk[i] = TGswKey::encrypt(key_in[i]) (src/lwe.rs:487-490) for k = 1, in the layout of
+// tfhe_hip_load_keys ([n][l][2][2][N], first N coefficients of every polynomial).
+// encrypt_zero fills row 0 only (src/tgsw.rs:118-127); TLweSample::encrypt_zero
+// (src/tlwe.rs:112-134) multiplies the key with the sample's old, all-zero polynomials, so
+// the body is the Gaussian polynomial left-padded to 2N-1 coefficients: of its first N
+// coefficients only the last one, the first Gaussian draw, is non-zero.  add_mu_int_h
+// (src/tgsw.rs:129-167) with h = [l, 0, ...] (src/tgsw.rs:43-48) then adds key_in[i] * l to
+// coefficient 0 of both polynomials of both row-0 samples.  One workgroup per (i, column).
+__global__ __launch_bounds__(256) void keygen_bk_kernel(ChaChaKey key, int l, double alpha,
+                                                        const int32_t* __restrict__ lwe_key,
+                                                        int32_t* __restrict__ bk) {
+  const int i = blockIdx.x >> 1, col = blockIdx.x & 1;
+  const uint64_t stream = (uint64_t)blockIdx.x;
+  int32_t* sample0 = bk + (((size_t)i * l + 0) * 2 + col) * 2 * kN;       // row 0, column col
+  const int32_t mu_h = (int32_t)((uint32_t)lwe_key[i] * (uint32_t)l);
+  // mask polynomial: uniform (64 keystream blocks), coefficient 0 += key bit * l
+  for (int b0 = threadIdx.x; b0 < kN / 16; b0 += blockDim.x) {
+    uint32_t blk[16];
+    chacha20_block(key, (uint32_t)b0, kRngBkMask, stream, blk);
+    for (int e = 0; e < 16; e++) {
+      const int x = b0 * 16 + e;
+      sample0[x] = x == 0 ? wadd((int32_t)blk[e], mu_h) : (int32_t)blk[e];
+    }
+  }
+  // body polynomial: [key bit * l, 0 ... 0, g0]
+  for (int x = threadIdx.x; x < kN; x += blockDim.x) sample0[kN + x] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t blk[16];
+    chacha20_block(key, 0, kRngBkNoise, stream, blk);
+    sample0[kN + kN - 1] = f64_to_torus32(alpha * normal_from_words(blk));   // gaussian32(0, alpha)
+    sample0[kN] = wadd(sample0[kN], mu_h);
+  }
+  // rows 1 .. l-1 of this column stay zero (src/tgsw.rs:108-116)
+  for (int p = 1; p < l; p++) {
+    int32_t* z = bk + (((size_t)i * l + p) * 2 + col) * 2 * kN;
+    for (int x = threadIdx.x; x < 2 * kN; x += blockDim.x) z[x] = 0;
+  }
+}
+
 }  // namespace
 
 // Scratch of tfhe_hip_gate_dev_noalloc, the entry point that allocates nothing:
@@ -1512,6 +1731,61 @@ int tfhe_hip_key_blob_sizes(const tfhe_hip_params* params, size_t* bk_bytes, siz
   return 0;
 }
 
+}  // extern "C"
+
+namespace {
+
+// Key material in DEVICE memory, in the layouts of tfhe_hip_load_keys (ks_var may be
+// NULL = zeros), to the two device blobs the kernels read: the bootstrapping key in
+// the FFT domain, the key-switch key as padded rows followed by its variances.
+int keys_from_device(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, const int32_t* bk_dev,
+                     const int32_t* ks_a_dev, const int32_t* ks_b_dev, const double* ks_var_dev) {
+  if (int rc = alloc_keys(ctx, params)) return rc;
+  const tfhe_hip_params& P = ctx->P;
+  {
+    const size_t count = (size_t)P.n * P.l * 2;            // (i, row, col) triples
+    const unsigned grid = (unsigned)((count + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(bk_fft_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, bk_dev, ctx->tables,
+                       ctx->bkfft, (int)count);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  {
+    const size_t rows = (size_t)P.n_ks * P.ks_t * 4;
+    const size_t total = rows * (size_t)ctx->row_stride;
+    hipLaunchKernelGGL(ks_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       ks_a_dev, ks_b_dev, P.n, ctx->row_stride, rows, (int32_t*)ctx->ksblob);
+    HIP_TRY(ctx, hipGetLastError());
+    if (ks_var_dev)
+      HIP_TRY(ctx, hipMemcpyAsync(ctx->ksblob + ctx->ks_rows_bytes, ks_var_dev, rows * sizeof(double),
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+    else
+      HIP_TRY(ctx, hipMemsetAsync(ctx->ksblob + ctx->ks_rows_bytes, 0, rows * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(ks_var_zero_kernel, dim3((unsigned)((rows / 4 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (double*)(ctx->ksblob + ctx->ks_rows_bytes), rows);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->have_keys = true;
+  return 0;
+}
+
+struct KeySizes {
+  size_t bk, ks_rows, ks_a, ks_b, ks_var;     // bytes of the raw (time-domain) arrays
+};
+KeySizes raw_key_sizes(const tfhe_hip_params* p) {
+  KeySizes z;
+  z.bk = (size_t)p->n * p->l * 4 * kN * sizeof(int32_t);
+  z.ks_rows = (size_t)p->n_ks * p->ks_t * 4;
+  z.ks_a = z.ks_rows * p->n * sizeof(int32_t);
+  z.ks_b = z.ks_rows * sizeof(int32_t);
+  z.ks_var = z.ks_rows * sizeof(double);
+  return z;
+}
+
+}  // namespace
+
+extern "C" {
+
 int tfhe_hip_load_keys(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, const int32_t* bk,
                        const int32_t* ks_a, const int32_t* ks_b, const double* ks_var) {
   if (!ctx) return TFHE_HIP_ERR_ARG;
@@ -1519,47 +1793,107 @@ int tfhe_hip_load_keys(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, const i
   if (!bk || !ks_a || !ks_b) return fail(ctx, TFHE_HIP_ERR_ARG, "key pointer is NULL");
   if (!ctx->shards.empty()) return tfhe_detail::load_keys_multi(ctx, params, bk, ks_a, ks_b, ks_var);
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  if (int rc = alloc_keys(ctx, params)) return rc;
-  const tfhe_hip_params& P = ctx->P;
-  // bootstrapping key -> FFT domain
-  {
-    const size_t count = (size_t)P.n * P.l * 2;            // (i, row, col) triples
-    const size_t bytes = count * 2 * kN * sizeof(int32_t);
-    DevBuf raw;
-    HIP_TRY(ctx, hipMalloc(&raw.p, bytes));
-    HIP_TRY(ctx, hipMemcpyAsync(raw.p, bk, bytes, hipMemcpyHostToDevice, ctx->stream));
-    const unsigned grid = (unsigned)((count + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL(bk_fft_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, (const int32_t*)raw.p,
-                       ctx->tables, ctx->bkfft, (int)count);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->have_keys = false;
+  const KeySizes z = raw_key_sizes(params);
+  DevBuf dbk, da, db, dv;
+  HIP_TRY(ctx, hipMalloc(&dbk.p, z.bk));
+  HIP_TRY(ctx, hipMalloc(&da.p, z.ks_a));
+  HIP_TRY(ctx, hipMalloc(&db.p, z.ks_b));
+  HIP_TRY(ctx, hipMemcpyAsync(dbk.p, bk, z.bk, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(da.p, ks_a, z.ks_a, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(db.p, ks_b, z.ks_b, hipMemcpyHostToDevice, ctx->stream));
+  if (ks_var) {
+    HIP_TRY(ctx, hipMalloc(&dv.p, z.ks_var));
+    HIP_TRY(ctx, hipMemcpyAsync(dv.p, ks_var, z.ks_var, hipMemcpyHostToDevice, ctx->stream));
   }
-  // key-switch key -> padded rows + variances
-  {
-    const size_t rows = (size_t)P.n_ks * P.ks_t * 4;
-    DevBuf da, db;
-    HIP_TRY(ctx, hipMalloc(&da.p, rows * P.n * sizeof(int32_t)));
-    HIP_TRY(ctx, hipMalloc(&db.p, rows * sizeof(int32_t)));
-    HIP_TRY(ctx, hipMemcpyAsync(da.p, ks_a, rows * P.n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(ctx, hipMemcpyAsync(db.p, ks_b, rows * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    const size_t total = rows * (size_t)ctx->row_stride;
-    hipLaunchKernelGGL(ks_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (const int32_t*)da.p, (const int32_t*)db.p, P.n, ctx->row_stride, rows,
-                       (int32_t*)ctx->ksblob);
-    HIP_TRY(ctx, hipGetLastError());
-    if (ks_var)
-      HIP_TRY(ctx, hipMemcpyAsync(ctx->ksblob + ctx->ks_rows_bytes, ks_var, rows * sizeof(double),
-                                  hipMemcpyHostToDevice, ctx->stream));
-    else
-      HIP_TRY(ctx, hipMemsetAsync(ctx->ksblob + ctx->ks_rows_bytes, 0, rows * sizeof(double), ctx->stream));
-    hipLaunchKernelGGL(ks_var_zero_kernel, dim3((unsigned)((rows / 4 + 255) / 256)), dim3(256), 0, ctx->stream,
-                       (double*)(ctx->ksblob + ctx->ks_rows_bytes), rows);
-    HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-  }
-  ctx->have_keys = true;
+  return keys_from_device(ctx, params, (const int32_t*)dbk.p, (const int32_t*)da.p, (const int32_t*)db.p,
+                          (const double*)dv.p);
+}
+
+int tfhe_hip_keygen_stream(tfhe_hip_ctx* ctx, const uint8_t seed[32], uint32_t purpose, uint64_t stream,
+                           uint32_t first_block, uint32_t* out, size_t nblocks) {
+  if (!ctx) return TFHE_HIP_ERR_ARG;
+  if (!seed || !out) return fail(ctx, TFHE_HIP_ERR_ARG, "pointer is NULL");
+  if (nblocks == 0) return 0;
+  tfhe_hip_ctx* c = ctx->shards.empty() ? ctx : ctx->shards[0];
+  HIP_TRY(ctx, hipSetDevice(c->device));
+  ChaChaKey key;
+  memcpy(key.w, seed, 32);
+  DevBuf d;
+  HIP_TRY(ctx, hipMalloc(&d.p, nblocks * 64));
+  hipLaunchKernelGGL(keygen_stream_kernel, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, c->stream,
+                     key, purpose, stream, first_block, (uint32_t*)d.p, nblocks);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(out, d.p, nblocks * 64, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(c->stream));
   return 0;
 }
+
+int tfhe_hip_generate_keys(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, double ks_stdev,
+                           double bk_stdev, const uint8_t seed[32], int32_t* lwe_key, int32_t* tlwe_key,
+                           int32_t* bk_out, int32_t* ks_a_out, int32_t* ks_b_out, double* ks_var_out) {
+  if (!ctx) return TFHE_HIP_ERR_ARG;
+  if (int rc = check_params(ctx, params)) return rc;
+  if (!seed || !lwe_key) return fail(ctx, TFHE_HIP_ERR_ARG, "seed or secret-key pointer is NULL");
+  if (!(ks_stdev >= 0.0) || !(bk_stdev >= 0.0)) return fail(ctx, TFHE_HIP_ERR_ARG, "standard deviations must be >= 0");
+  tfhe_hip_ctx* c = ctx->shards.empty() ? ctx : ctx->shards[0];     // generate on the first GPU
+  HIP_TRY(ctx, hipSetDevice(c->device));
+  c->have_keys = false;
+  ctx->have_keys = false;
+  const tfhe_hip_params& P = *params;
+  ChaChaKey key;
+  memcpy(key.w, seed, 32);
+  const KeySizes z = raw_key_sizes(params);
+  const int tlwe_count = (P.k + 1) * P.N;
+  const int size_ks = P.n_ks * P.ks_t * ((1 << P.ks_base_bit) - 1);
+  const int noise_blocks = (size_ks + 255) / 256;
+  DevBuf dbk, da, db, dv, dkey, dtkey, dnoise, dpartial;
+  auto run = [&]() -> int {
+    HIP_TRY(c, hipMalloc(&dbk.p, z.bk));
+    HIP_TRY(c, hipMalloc(&da.p, z.ks_a));
+    HIP_TRY(c, hipMalloc(&db.p, z.ks_b));
+    HIP_TRY(c, hipMalloc(&dv.p, z.ks_var));
+    HIP_TRY(c, hipMalloc(&dkey.p, (size_t)P.n * 4));
+    HIP_TRY(c, hipMalloc(&dtkey.p, (size_t)tlwe_count * 4));
+    HIP_TRY(c, hipMalloc(&dnoise.p, (size_t)size_ks * 8));
+    HIP_TRY(c, hipMalloc(&dpartial.p, (size_t)(noise_blocks + 1) * 8));
+    int32_t* k_lwe = (int32_t*)dkey.p;
+    int32_t* k_tlwe = (int32_t*)dtkey.p;
+    double* partial = (double*)dpartial.p;
+    const int secret_blocks = (P.n + 15) / 16 + (tlwe_count + 15) / 16;
+    hipLaunchKernelGGL(keygen_secret_kernel, dim3((secret_blocks + 255) / 256), dim3(256), 0, c->stream, key,
+                       P.n, tlwe_count, k_lwe, k_tlwe);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(keygen_ks_noise_kernel, dim3(noise_blocks), dim3(256), 0, c->stream, key, ks_stdev,
+                       size_ks, (double*)dnoise.p, partial);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(keygen_ks_mean_kernel, dim3(1), dim3(64), 0, c->stream, (const double*)partial,
+                       noise_blocks, size_ks, partial + noise_blocks);
+    HIP_TRY(c, hipGetLastError());
+    // LweKey::extract (src/lwe.rs:369-386): the first k polynomials of the TLWE key; the
+    // key-switch key has n_ks rows (src/lwe.rs:461) and reads bits 0 .. n_ks-1 of it
+    hipLaunchKernelGGL(keygen_ks_kernel, dim3((unsigned)z.ks_rows), dim3(256), 0, c->stream, key, P.n, P.ks_t,
+                       P.ks_base_bit, ks_stdev, (const int32_t*)k_lwe, (const int32_t*)k_tlwe,
+                       (const double*)dnoise.p, (const double*)(partial + noise_blocks), (int32_t*)da.p,
+                       (int32_t*)db.p, (double*)dv.p);
+    HIP_TRY(c, hipGetLastError());
+    hipLaunchKernelGGL(keygen_bk_kernel, dim3((unsigned)P.n * 2), dim3(256), 0, c->stream, key, P.l, bk_stdev,
+                       (const int32_t*)k_lwe, (int32_t*)dbk.p);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(lwe_key, k_lwe, (size_t)P.n * 4, hipMemcpyDeviceToHost, c->stream));
+    if (tlwe_key) HIP_TRY(c, hipMemcpyAsync(tlwe_key, k_tlwe, (size_t)tlwe_count * 4, hipMemcpyDeviceToHost, c->stream));
+    if (bk_out) HIP_TRY(c, hipMemcpyAsync(bk_out, dbk.p, z.bk, hipMemcpyDeviceToHost, c->stream));
+    if (ks_a_out) HIP_TRY(c, hipMemcpyAsync(ks_a_out, da.p, z.ks_a, hipMemcpyDeviceToHost, c->stream));
+    if (ks_b_out) HIP_TRY(c, hipMemcpyAsync(ks_b_out, db.p, z.ks_b, hipMemcpyDeviceToHost, c->stream));
+    if (ks_var_out) HIP_TRY(c, hipMemcpyAsync(ks_var_out, dv.p, z.ks_var, hipMemcpyDeviceToHost, c->stream));
+    return keys_from_device(c, params, (const int32_t*)dbk.p, (const int32_t*)da.p, (const int32_t*)db.p,
+                            (const double*)dv.p);
+  };
+  if (int rc = run()) return c == ctx ? rc : fail(ctx, rc, c->err);
+  if (c != ctx) return tfhe_detail::replicate_keys_multi(ctx, params);
+  return 0;
+}
+
 
 int tfhe_hip_export_keys_dev(tfhe_hip_ctx* ctx, void* bk_blob_dev, void* ks_blob_dev) {
   if (int rc = need_keys(ctx)) return rc;

@@ -135,6 +135,39 @@ class Engine:
                                                 _p(ks_b), _p(ks_var)))
         self.params = params
 
+    def generate_keys(self, params, ks_stdev, bk_stdev, seed, export=True):
+        """generate_keys on the GPU (tfhe_hip_generate_keys).  seed: 32 bytes.  Returns a dict
+        with the secret keys (lwe_key [n], tlwe_key [k+1][N]) and, with export, the cloud key
+        arrays bk, ks_a, ks_b, ks_var in the layouts of load_keys.  The engine holds the keys."""
+        seed = np.frombuffer(bytes(seed), dtype=np.uint8)
+        if seed.size != 32:
+            raise ValueError("seed must be 32 bytes")
+        seed = np.ascontiguousarray(seed)
+        base = 1 << params.ks_base_bit
+        out = {"lwe_key": np.empty(params.n, np.int32),
+               "tlwe_key": np.empty((params.k + 1, params.N), np.int32)}
+        if export:
+            out["bk"] = np.empty((params.n, params.l, params.k + 1, params.k + 1, params.N), np.int32)
+            out["ks_a"] = np.empty((params.n_ks, params.ks_t, base, params.n), np.int32)
+            out["ks_b"] = np.empty((params.n_ks, params.ks_t, base), np.int32)
+            out["ks_var"] = np.empty((params.n_ks, params.ks_t, base), np.float64)
+        self._check(self.lib.tfhe_hip_generate_keys(
+            self.ctx, C.byref(params), float(ks_stdev), float(bk_stdev), _p(seed), _p(out["lwe_key"]),
+            _p(out["tlwe_key"]), _p(out.get("bk")), _p(out.get("ks_a")), _p(out.get("ks_b")),
+            _p(out.get("ks_var"))))
+        self.params = params
+        return out
+
+    def keygen_stream(self, seed, purpose, stream, first_block, nblocks):
+        """Raw ChaCha20 keystream words [nblocks][16] behind generate_keys (test hook)."""
+        seed = np.ascontiguousarray(np.frombuffer(bytes(seed), dtype=np.uint8))
+        if seed.size != 32:
+            raise ValueError("seed must be 32 bytes")
+        out = np.empty((nblocks, 16), np.uint32)
+        self._check(self.lib.tfhe_hip_keygen_stream(self.ctx, _p(seed), purpose, stream, first_block,
+                                                    _p(out), nblocks))
+        return out
+
     def pack_key_file(self, params, bk, ks_a, ks_b, ks_var=None):
         """The flat key image (bytes) that load_key_file / tfhe_hip_load_keys_blob read."""
         bk, ks_a, ks_b, ks_var = self._key_arrays(params, bk, ks_a, ks_b, ks_var)
