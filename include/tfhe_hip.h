@@ -288,6 +288,29 @@ int tfhe_hip_circuit_add_dev(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_
                              int32_t* carry_a, int32_t* carry_b, double* sum_var, double* carry_var,
                              size_t count, int bits);
 
+/* circuits::compare (src/circuits/circuits.rs:33-47, a <= b, the first element
+ * of the slices compared first) and circuits::eq (src/circuits/circuits.rs:50-70)
+ * on `count` independent pairs of `bits`-bit operands, level by level like
+ * tfhe_hip_circuit_add: the xor of every bit of every instance is one blind
+ * rotation, then the carry chain (one mux per bit) or the and-fold runs one
+ * level of `count` gates per bit; intermediate ciphertexts stay on the GPU.
+ * Operands bit-sliced as for tfhe_hip_circuit_add; out_a [count][n], out_b
+ * [count], out_var [count] or NULL.  compare with bits = 0 returns
+ * constant(true), as the reference's loop does; eq needs bits >= 1 (the
+ * reference asserts that its operands are not empty). */
+int tfhe_hip_circuit_compare(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_t* a_b,
+                             const int32_t* b_a, const int32_t* b_b, int32_t* out_a, int32_t* out_b,
+                             double* out_var, size_t count, int bits);
+int tfhe_hip_circuit_compare_dev(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_t* a_b,
+                                 const int32_t* b_a, const int32_t* b_b, int32_t* out_a,
+                                 int32_t* out_b, double* out_var, size_t count, int bits);
+int tfhe_hip_circuit_eq(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_t* a_b, const int32_t* b_a,
+                        const int32_t* b_b, int32_t* out_a, int32_t* out_b, double* out_var,
+                        size_t count, int bits);
+int tfhe_hip_circuit_eq_dev(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_t* a_b,
+                            const int32_t* b_a, const int32_t* b_b, int32_t* out_a, int32_t* out_b,
+                            double* out_var, size_t count, int bits);
+
 /* poly_multiplier / torus_polynomial_mul_r (src/numerics.rs:138-155,185-261)
  * on B independent pairs of N-coefficient polynomials d [B][N], s [B][N].
  * accumulate == 0: out [B][2N-1] = the full saturated product;

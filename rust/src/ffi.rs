@@ -324,6 +324,54 @@ extern "C" {
         count: usize,
         bits: c_int,
     ) -> c_int;
+    pub fn tfhe_hip_circuit_compare(
+        ctx: *mut TfheHipCtx,
+        a_a: *const i32,
+        a_b: *const i32,
+        b_a: *const i32,
+        b_b: *const i32,
+        out_a: *mut i32,
+        out_b: *mut i32,
+        out_var: *mut f64,
+        count: usize,
+        bits: c_int,
+    ) -> c_int;
+    pub fn tfhe_hip_circuit_compare_dev(
+        ctx: *mut TfheHipCtx,
+        a_a: *const i32,
+        a_b: *const i32,
+        b_a: *const i32,
+        b_b: *const i32,
+        out_a: *mut i32,
+        out_b: *mut i32,
+        out_var: *mut f64,
+        count: usize,
+        bits: c_int,
+    ) -> c_int;
+    pub fn tfhe_hip_circuit_eq(
+        ctx: *mut TfheHipCtx,
+        a_a: *const i32,
+        a_b: *const i32,
+        b_a: *const i32,
+        b_b: *const i32,
+        out_a: *mut i32,
+        out_b: *mut i32,
+        out_var: *mut f64,
+        count: usize,
+        bits: c_int,
+    ) -> c_int;
+    pub fn tfhe_hip_circuit_eq_dev(
+        ctx: *mut TfheHipCtx,
+        a_a: *const i32,
+        a_b: *const i32,
+        b_a: *const i32,
+        b_b: *const i32,
+        out_a: *mut i32,
+        out_b: *mut i32,
+        out_var: *mut f64,
+        count: usize,
+        bits: c_int,
+    ) -> c_int;
     pub fn tfhe_hip_polymul(
         ctx: *mut TfheHipCtx,
         d: *const i32,

@@ -457,3 +457,58 @@ def test_multi_context_rccl_replication_in_a_fresh_process():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0 and "DONE" in r.stdout, r.stdout + r.stderr
     assert "MSG keys replicated over RCCL" in r.stdout, r.stdout + r.stderr
+
+
+# ---- circuits::compare and circuits::eq, level-batched -----------------------------------------
+
+def _oracle_compare(P, K, a, b, mode):
+    """compare / le of /root/reference/src/circuits/circuits.rs:33-47 composed of oracle gates."""
+    carry = (np.zeros(P.n, np.int32), np.int32(1 << 29), 0.0)         # constant(true)
+    for x, y in zip(a, b):
+        cond = orc.gate(P, "xor", K, x, y, None, mode)
+        carry = orc.gate(P, "mux", K, cond, y, carry, mode)
+    return carry
+
+
+def _oracle_eq(P, K, a, b, mode):
+    """eq / eq_bit of /root/reference/src/circuits/circuits.rs:50-70 composed of oracle gates."""
+    one = (np.zeros(P.n, np.int32), np.int32(1 << 29), 0.0)
+    bits = [orc.gate(P, "xor", K, orc.gate(P, "xor", K, x, y, None, mode), one, None, mode) for x, y in zip(a, b)]
+    res = one
+    for bit in bits:
+        res = orc.gate(P, "and", K, res, bit, None, mode)
+    return res
+
+
+@pytest.mark.parametrize("tag,bits,count", [((2, 10), 4, 5), ((3, 7), 3, 2), ((2, 10), 1, 1), ((2, 10), 0, 3)])
+def test_circuit_compare_and_eq(eng, tag, bits, count):
+    import tfhe_amd
+    l, bg = tag
+    P = orc.small_params(n=6, l=l, bg_bit=bg)
+    K = orc.generate_synthetic_keys(P, 2500)
+    _load(eng, P, K)
+    A = (orc.uniform_i32(2501, (bits, count, P.n)), orc.uniform_i32(2502, (bits, count)))
+    Bv = (orc.uniform_i32(2503, (bits, count, P.n)), orc.uniform_i32(2504, (bits, count)))
+    m = tfhe_amd.Engine([0, 0])
+    try:
+        m.load_keys(_hip_params(P), K["bk"], K["ks_a"], K["ks_b"], K["ks_var"])
+        ca, cb, cv = eng.circuit_compare(A, Bv, want_var=True)
+        for x, y in zip((ca, cb, cv), m.circuit_compare(A, Bv, want_var=True)):
+            assert (x == y).all()
+        if bits >= 1:
+            ea, eb, ev = eng.circuit_eq(A, Bv, want_var=True)
+            for x, y in zip((ea, eb, ev), m.circuit_eq(A, Bv, want_var=True)):
+                assert (x == y).all()
+        else:
+            with pytest.raises(tfhe_amd.TfheHipError, match="at least one bit"):
+                eng.circuit_eq(A, Bv)
+    finally:
+        m.close()
+    for c in range(count):
+        a = [(A[0][i, c], A[1][i, c], 0.0) for i in range(bits)]
+        b = [(Bv[0][i, c], Bv[1][i, c], 0.0) for i in range(bits)]
+        w = _oracle_compare(P, K, a, b, orc.MUL_EXACT)
+        assert (ca[c] == w[0]).all() and cb[c] == w[1] and cv[c] == w[2], c
+        if bits >= 1:
+            w = _oracle_eq(P, K, a, b, orc.MUL_EXACT)
+            assert (ea[c] == w[0]).all() and eb[c] == w[1] and ev[c] == w[2], c

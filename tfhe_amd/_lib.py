@@ -28,6 +28,7 @@ SYMBOLS = [
     "tfhe_hip_polymul_margin", "tfhe_hip_polymul_margin_dev", "tfhe_hip_extprod_margin",
     "tfhe_hip_extprod_dev", "tfhe_hip_blind_rotate_dev", "tfhe_hip_gate_dev_noalloc",
     "tfhe_hip_generate_keys", "tfhe_hip_keygen_stream",
+    "tfhe_hip_circuit_compare", "tfhe_hip_circuit_compare_dev", "tfhe_hip_circuit_eq", "tfhe_hip_circuit_eq_dev",
 ]
 NO_INT_RESULT = ("tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_samples_free", "tfhe_hip_samples_count")
 
@@ -75,6 +76,9 @@ def load():
         getattr(lib, name).argtypes = [vp, i32p, i32p, i32p, C.c_int, sz]
     for name in ("tfhe_hip_circuit_add", "tfhe_hip_circuit_add_dev"):
         getattr(lib, name).argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i32p, i32p, i32p, f64p, f64p, sz, C.c_int]
+    for name in ("tfhe_hip_circuit_compare", "tfhe_hip_circuit_compare_dev", "tfhe_hip_circuit_eq",
+                 "tfhe_hip_circuit_eq_dev"):
+        getattr(lib, name).argtypes = [vp, i32p, i32p, i32p, i32p, i32p, i32p, f64p, sz, C.c_int]
     lib.tfhe_hip_profile_enable.argtypes = [vp, C.c_int]
     lib.tfhe_hip_profile_read.argtypes = [vp, C.POINTER(C.c_double * 3), C.POINTER(C.c_int * 3)]
     lib.tfhe_hip_extprod.argtypes = [vp, i32p, C.c_int, i32p, sz]

@@ -299,6 +299,60 @@ int circuit_add_1(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_t* a_b, con
   return 0;
 }
 
+// circuits::compare (which = 0) / circuits::eq (which = 1): bit-sliced operands
+// [bits][stride][...] of the caller, instances [0, count) of every slice; one sample per
+// instance comes back.
+int circuit_reduce_1(tfhe_hip_ctx* ctx, int which, const int32_t* a_a, const int32_t* a_b,
+                     const int32_t* b_a, const int32_t* b_b, int32_t* out_a, int32_t* out_b,
+                     double* out_var, size_t count, int bits, size_t stride) {
+  if (int rc = ready(ctx)) return rc;
+  const size_t n = ctx->P.n, nb = (size_t)(bits > 0 ? bits : 0);
+  const size_t ma = nb * count * n * 4, mb = nb * count * 4;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t o_aa = take(ma), o_ab = take(mb), o_ba = take(ma), o_bb = take(mb);
+  const size_t o_oa = take(count * n * 4), o_ob = take(count * 4), o_ov = take(count * 8);
+  if (int rc = ensure_stage(ctx, off, false)) return rc;
+  char* dev = (char*)ctx->stage_dev;
+  auto copy2d = [&](void* dst, size_t dpitch, const void* src, size_t spitch, size_t width) -> hipError_t {
+    if (nb == 0 || width == 0) return hipSuccess;
+    return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, nb, hipMemcpyHostToDevice, ctx->stream);
+  };
+  HIP_TRY(ctx, copy2d(dev + o_aa, count * n * 4, a_a, stride * n * 4, count * n * 4));
+  HIP_TRY(ctx, copy2d(dev + o_ab, count * 4, a_b, stride * 4, count * 4));
+  HIP_TRY(ctx, copy2d(dev + o_ba, count * n * 4, b_a, stride * n * 4, count * n * 4));
+  HIP_TRY(ctx, copy2d(dev + o_bb, count * 4, b_b, stride * 4, count * 4));
+  auto fn = which == 0 ? tfhe_hip_circuit_compare_dev : tfhe_hip_circuit_eq_dev;
+  if (int rc = fn(ctx, (int32_t*)(dev + o_aa), (int32_t*)(dev + o_ab), (int32_t*)(dev + o_ba),
+                  (int32_t*)(dev + o_bb), (int32_t*)(dev + o_oa), (int32_t*)(dev + o_ob),
+                  out_var ? (double*)(dev + o_ov) : nullptr, count, bits)) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(out_a, dev + o_oa, count * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipMemcpyAsync(out_b, dev + o_ob, count * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (out_var)
+    HIP_TRY(ctx, hipMemcpyAsync(out_var, dev + o_ov, count * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int circuit_reduce(tfhe_hip_ctx* ctx, int which, const int32_t* a_a, const int32_t* a_b,
+                   const int32_t* b_a, const int32_t* b_b, int32_t* out_a, int32_t* out_b,
+                   double* out_var, size_t count, int bits) {
+  if (!ctx) return TFHE_HIP_ERR_ARG;
+  if (!ctx->have_keys) return fail(ctx, TFHE_HIP_ERR_STATE, "no keys loaded");
+  if (which == 0 ? bits < 0 : bits < 1)
+    return fail(ctx, TFHE_HIP_ERR_ARG, which == 0 ? "bits must be >= 0" : "eq needs at least one bit");
+  if (count == 0) return 0;
+  if (!out_a || !out_b || (bits > 0 && (!a_a || !a_b || !b_a || !b_b)))
+    return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
+  if (!multi(ctx))
+    return circuit_reduce_1(ctx, which, a_a, a_b, b_a, b_b, out_a, out_b, out_var, count, bits, count);
+  const size_t n = ctx->P.n;      // shard by instance
+  return run_sharded(ctx, count, [=](tfhe_hip_ctx* s, size_t lo, size_t hi) {
+    return circuit_reduce_1(s, which, at(a_a, lo * n), at(a_b, lo), at(b_a, lo * n), at(b_b, lo),
+                            out_a + lo * n, out_b + lo, at(out_var, lo), hi - lo, bits, count);
+  });
+}
+
 int polymul_1(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, int32_t* out, double* margin,
               int accumulate, size_t B) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -402,6 +456,18 @@ int tfhe_hip_circuit_add(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_t* a
                          at(sum_b, lo), carry_a + lo * n, carry_b + lo, at(sum_var, lo),
                          at(carry_var, lo), hi - lo, bits, count);
   });
+}
+
+int tfhe_hip_circuit_compare(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_t* a_b,
+                             const int32_t* b_a, const int32_t* b_b, int32_t* out_a, int32_t* out_b,
+                             double* out_var, size_t count, int bits) {
+  return circuit_reduce(ctx, 0, a_a, a_b, b_a, b_b, out_a, out_b, out_var, count, bits);
+}
+
+int tfhe_hip_circuit_eq(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_t* a_b, const int32_t* b_a,
+                        const int32_t* b_b, int32_t* out_a, int32_t* out_b, double* out_var,
+                        size_t count, int bits) {
+  return circuit_reduce(ctx, 1, a_a, a_b, b_a, b_b, out_a, out_b, out_var, count, bits);
 }
 
 int tfhe_hip_polymul(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, int32_t* out,

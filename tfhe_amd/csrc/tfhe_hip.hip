@@ -2098,6 +2098,94 @@ int tfhe_hip_circuit_add_dev(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_
 }
 
 
+// circuits::compare (src/circuits/circuits.rs:33-47: a <= b) on `count` independent
+// operand pairs: condition_i = xor(a_i, b_i) of every bit of every instance in one
+// blind rotation, then per bit carry = mux(condition_i, b_i, carry) starting from
+// constant(true) (le, circuits.rs:44-47), one blind rotation of 2 count ciphertexts each.
+int tfhe_hip_circuit_compare_dev(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_t* a_b,
+                                 const int32_t* b_a, const int32_t* b_b, int32_t* out_a,
+                                 int32_t* out_b, double* out_var, size_t count, int bits) {
+  if (int rc = need_keys(ctx)) return rc;
+  if (bits < 0) return fail(ctx, TFHE_HIP_ERR_ARG, "bits must be >= 0");
+  if (count == 0) return 0;
+  if (!out_a || !out_b || (bits > 0 && (!a_a || !a_b || !b_a || !b_b)))
+    return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
+  const size_t n = ctx->P.n, sa = count * n, sb = count, slice = sa + sb;
+  // workspace: condition [bits] slices, carry ping-pong 2 slices
+  if (int rc = ensure_work(ctx, ((size_t)bits + 2) * slice * sizeof(int32_t))) return rc;
+  int32_t* w = (int32_t*)ctx->work;
+  int32_t *x_a = w, *x_b = x_a + (size_t)bits * sa;
+  int32_t *c0_a = x_b + (size_t)bits * sb, *c0_b = c0_a + sa, *c1_a = c0_b + sb, *c1_b = c1_a + sa;
+  constexpr size_t kMaxGroup = 65536;
+  const int bits_per_group = (int)std::max<size_t>(1, kMaxGroup / count);
+  for (int i0 = 0; i0 < bits; i0 += bits_per_group) {
+    const size_t nb = (size_t)std::min(bits_per_group, bits - i0);
+    const GateItem item = {TFHE_HIP_XOR, a_a + i0 * sa, a_b + i0 * sb, b_a + i0 * sa, b_b + i0 * sb,
+                           x_a + i0 * sa, x_b + i0 * sb, nullptr, nb * count};
+    if (int rc = run_gate_group(ctx, &item, 1)) return rc;
+  }
+  int32_t *cin_a = bits == 0 ? out_a : c0_a, *cin_b = bits == 0 ? out_b : c0_b, *cout_a = c1_a, *cout_b = c1_b;
+  if (int rc = tfhe_hip_constant_dev(ctx, 1, cin_a, cin_b, bits == 0 ? out_var : nullptr, count)) return rc;
+  for (int i = 0; i < bits; i++) {
+    const bool last = i == bits - 1;
+    if (int rc = gate_on_device(ctx, false, TFHE_HIP_MUX, x_a + i * sa, x_b + i * sb, b_a + i * sa,
+                                b_b + i * sb, cin_a, cin_b, last ? out_a : cout_a, last ? out_b : cout_b,
+                                last ? out_var : nullptr, count)) return rc;
+    std::swap(cin_a, cout_a);
+    std::swap(cin_b, cout_b);
+  }
+  return 0;
+}
+
+// circuits::eq (src/circuits/circuits.rs:50-63) on `count` independent operand pairs:
+// eq_bit(a_i, b_i) = xor(xor(a_i, b_i), constant(true)) (circuits.rs:66-70) of every bit of
+// every instance in two blind rotations, then the fold res = and(res, bit_i) from
+// constant(true), one blind rotation of count ciphertexts per bit.  The reference asserts
+// that the operands are not empty.
+int tfhe_hip_circuit_eq_dev(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_t* a_b,
+                            const int32_t* b_a, const int32_t* b_b, int32_t* out_a, int32_t* out_b,
+                            double* out_var, size_t count, int bits) {
+  if (int rc = need_keys(ctx)) return rc;
+  if (bits < 1) return fail(ctx, TFHE_HIP_ERR_ARG, "eq needs at least one bit");
+  if (count == 0) return 0;
+  if (!out_a || !out_b || !a_a || !a_b || !b_a || !b_b)
+    return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
+  const size_t n = ctx->P.n, sa = count * n, sb = count, slice = sa + sb;
+  constexpr size_t kMaxGroup = 65536;
+  const int bits_per_group = (int)std::max<size_t>(1, kMaxGroup / count);
+  const size_t gb = (size_t)std::min(bits_per_group, bits);       // bits of the largest group
+  // workspace: x, e [bits] slices; constant(true) for one group; res ping-pong 2 slices
+  if (int rc = ensure_work(ctx, (2 * (size_t)bits + gb + 2) * slice * sizeof(int32_t))) return rc;
+  int32_t* w = (int32_t*)ctx->work;
+  int32_t *x_a = w, *x_b = x_a + (size_t)bits * sa;
+  int32_t *e_a = x_b + (size_t)bits * sb, *e_b = e_a + (size_t)bits * sa;
+  int32_t *one_a = e_b + (size_t)bits * sb, *one_b = one_a + gb * sa;
+  int32_t *r0_a = one_b + gb * sb, *r0_b = r0_a + sa, *r1_a = r0_b + sb, *r1_b = r1_a + sa;
+  if (int rc = tfhe_hip_constant_dev(ctx, 1, one_a, one_b, nullptr, gb * count)) return rc;
+  for (int i0 = 0; i0 < bits; i0 += bits_per_group) {
+    const size_t nb = (size_t)std::min(bits_per_group, bits - i0);
+    const GateItem x = {TFHE_HIP_XOR, a_a + i0 * sa, a_b + i0 * sb, b_a + i0 * sa, b_b + i0 * sb,
+                        x_a + i0 * sa, x_b + i0 * sb, nullptr, nb * count};
+    if (int rc = run_gate_group(ctx, &x, 1)) return rc;
+    const GateItem e = {TFHE_HIP_XOR, x_a + i0 * sa, x_b + i0 * sb, one_a, one_b, e_a + i0 * sa,
+                        e_b + i0 * sb, nullptr, nb * count};
+    if (int rc = run_gate_group(ctx, &e, 1)) return rc;
+  }
+  // the fold starts from constant(true): the first `count` entries of `one`
+  const int32_t *res_a = one_a, *res_b = one_b;
+  int32_t *nxt_a = r0_a, *nxt_b = r0_b, *alt_a = r1_a, *alt_b = r1_b;
+  for (int i = 0; i < bits; i++) {
+    const bool last = i == bits - 1;
+    const GateItem g = {TFHE_HIP_AND, res_a, res_b, e_a + i * sa, e_b + i * sb, last ? out_a : nxt_a,
+                        last ? out_b : nxt_b, last ? out_var : nullptr, count};
+    if (int rc = run_gate_group(ctx, &g, 1)) return rc;
+    res_a = nxt_a; res_b = nxt_b;
+    std::swap(nxt_a, alt_a);
+    std::swap(nxt_b, alt_b);
+  }
+  return 0;
+}
+
 int tfhe_hip_not_dev(tfhe_hip_ctx* ctx, const int32_t* a, const int32_t* b, const double* var,
                      int32_t* out_a, int32_t* out_b, double* var_out, size_t B) {
   if (int rc = need_keys(ctx)) return rc;

@@ -303,6 +303,29 @@ class Engine:
             return (sum_a, sum_b), (car_a, car_b), sv, cv
         return (sum_a, sum_b), (car_a, car_b)
 
+    def _circuit_reduce(self, fn, a, b, want_var):
+        a_a, a_b, b_a, b_b = _np(a[0]), _np(a[1]), _np(b[0]), _np(b[1])
+        if a_b.ndim != 2:
+            raise ValueError("bodies must be [bits][count]")
+        bits, count = a_b.shape
+        n = self.params.n
+        _want(a_a, (bits, count, n), "a masks")
+        _want(b_a, (bits, count, n), "b masks")
+        _want(b_b, (bits, count), "b bodies")
+        out_a, out_b = np.empty((count, n), np.int32), np.empty(count, np.int32)
+        var = np.empty(count, np.float64) if want_var else None
+        self._check(fn(self.ctx, _p(a_a), _p(a_b), _p(b_a), _p(b_b), _p(out_a), _p(out_b), _p(var),
+                       count, bits))
+        return (out_a, out_b, var) if want_var else (out_a, out_b)
+
+    def circuit_compare(self, a, b, want_var=False):
+        """circuits::compare (a <= b) on many instances; operands as for circuit_add."""
+        return self._circuit_reduce(self.lib.tfhe_hip_circuit_compare, a, b, want_var)
+
+    def circuit_eq(self, a, b, want_var=False):
+        """circuits::eq on many instances; operands as for circuit_add."""
+        return self._circuit_reduce(self.lib.tfhe_hip_circuit_eq, a, b, want_var)
+
     def polymul(self, d, s, accumulate_into=None):
         d, s = _np(d), _np(s)
         if d.ndim != 2 or d.shape[1] != 1024:
