@@ -362,20 +362,60 @@ inline LweSample tfhe_bootstrap(const CloudKey& bk, Torus32 mu, const LweSample&
 namespace circuits {
 
 namespace detail {
-// Less than or equal to comparator with carry input (circuits.rs:44-47).
-inline LweSample le(const LweSample& a, const LweSample& b, const LweSample& rim, const CloudKey& key) {
-  const LweSample condition = xor_(a, b, key);
-  return mux(condition, b, rim, key);
+// Bit-slices many operands: out_a [bits][count][n], out_b [bits][count].
+inline void bit_slice(const std::vector<std::vector<LweSample>>& x, size_t bits, size_t n, const char* what,
+                      std::vector<int32_t>& out_a, std::vector<int32_t>& out_b) {
+  const size_t count = x.size();
+  out_a.resize(bits * count * n);
+  out_b.resize(bits * count);
+  for (size_t c = 0; c < count; c++) {
+    if (x[c].size() != bits) throw std::runtime_error(std::string(what) + ": operands differ in length");
+    for (size_t i = 0; i < bits; i++) {
+      if (x[c][i].coefficients.size() != n) throw std::runtime_error(std::string(what) + ": sample size differs from n");
+      std::copy(x[c][i].coefficients.begin(), x[c][i].coefficients.end(), out_a.begin() + (i * count + c) * n);
+      out_b[i * count + c] = x[c][i].b;
+    }
+  }
+}
+
+// compare / eq on many operand pairs through the level-batched device executors.
+template <class Fn>
+inline std::vector<LweSample> reduce(Fn fn, const char* what, const std::vector<std::vector<LweSample>>& a,
+                                     const std::vector<std::vector<LweSample>>& b, const CloudKey& key) {
+  if (!key.device) throw std::runtime_error("CloudKey has no device context");
+  if (a.size() != b.size()) throw std::runtime_error(std::string(what) + ": numbers of operands differ");
+  const size_t count = a.size(), n = key.params.in_out_params.n;
+  if (count == 0) return {};
+  const size_t bits = a[0].size();
+  std::vector<int32_t> aa, ab, ba, bb;
+  bit_slice(a, bits, n, what, aa, ab);
+  bit_slice(b, bits, n, what, ba, bb);
+  std::vector<int32_t> oa(count * n), ob(count);
+  std::vector<double> ov(count);
+  key.device->check(fn(key.device->ctx, aa.data(), ab.data(), ba.data(), bb.data(), oa.data(), ob.data(),
+                       ov.data(), count, (int)bits));
+  std::vector<LweSample> out(count);
+  for (size_t c = 0; c < count; c++) {
+    out[c].coefficients.assign(oa.begin() + c * n, oa.begin() + (c + 1) * n);
+    out[c].b = ob[c];
+    out[c].current_variance = ov[c];
+  }
+  return out;
 }
 }  // namespace detail
 
-// `a <= b` on little-endian bit vectors (circuits.rs:33-41).
+// `a <= b` (circuits.rs:33-47) for many operand pairs at once: the xor of every bit of every
+// pair is one launch, then one mux level per bit.
+inline std::vector<LweSample> compare(const std::vector<std::vector<LweSample>>& a,
+                                      const std::vector<std::vector<LweSample>>& b, const CloudKey& key) {
+  return detail::reduce(tfhe_hip_circuit_compare, "compare", a, b, key);
+}
+
+// `a <= b` on bit vectors (circuits.rs:33-41).
 inline LweSample compare(const std::vector<LweSample>& a, const std::vector<LweSample>& b,
                          const CloudKey& key) {
-  LweSample carry = constant(true, key);
   if (a.size() != b.size()) throw std::runtime_error("compare: operands differ in length");
-  for (size_t i = 0; i < a.size(); i++) carry = detail::le(a[i], b[i], carry, key);
-  return carry;
+  return compare(std::vector<std::vector<LweSample>>{a}, std::vector<std::vector<LweSample>>{b}, key)[0];
 }
 
 // circuits.rs:65-69
@@ -384,15 +424,18 @@ inline LweSample eq_bit(const LweSample& a, const LweSample& b, const CloudKey& 
   return xor_(res, constant(true, key), key);
 }
 
-// circuits.rs:50-62; the per-bit equalities are independent and run as two batches.
+// Bitwise equality (circuits.rs:50-62) for many operand pairs at once.
+inline std::vector<LweSample> eq(const std::vector<std::vector<LweSample>>& a,
+                                 const std::vector<std::vector<LweSample>>& b, const CloudKey& key) {
+  if (!a.empty() && a[0].empty()) throw std::runtime_error("eq: empty operand");
+  return detail::reduce(tfhe_hip_circuit_eq, "eq", a, b, key);
+}
+
+// circuits.rs:50-62
 inline LweSample eq(const std::vector<LweSample>& a, const std::vector<LweSample>& b, const CloudKey& key) {
   if (a.empty()) throw std::runtime_error("eq: empty operand");
   if (a.size() != b.size()) throw std::runtime_error("eq: operands differ in length");
-  const std::vector<LweSample> ones(a.size(), constant(true, key));
-  const std::vector<LweSample> bits = xor_(xor_(a, b, key), ones, key);
-  LweSample res = constant(true, key);
-  for (const LweSample& bit : bits) res = and_(res, bit, key);
-  return res;
+  return eq(std::vector<std::vector<LweSample>>{a}, std::vector<std::vector<LweSample>>{b}, key)[0];
 }
 
 // circuits.rs:77-79
