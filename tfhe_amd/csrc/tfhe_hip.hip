@@ -64,6 +64,15 @@ struct StampCtx {
 #define TFHE_K1_DEPTH 4
 #endif
 
+// The isolated-product kernel the entry points launch: polymul2_kernel (one parked
+// spectrum, operands prefetched by LDS DMA) or polymul_kernel (the first form).
+#ifndef TFHE_POLYMUL_CHUNK
+#define TFHE_POLYMUL_CHUNK 4
+#endif
+#ifndef TFHE_POLYMUL_KERNEL
+#define TFHE_POLYMUL_KERNEL polymul2_kernel
+#endif
+
 // Where the accumulator of the blind rotation lives between uses: parked in
 // accumulation registers by hand (0) or left to the register allocator (1).
 #ifndef TFHE_ACC_VGPR
@@ -816,6 +825,191 @@ __global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __res
       margin[2 * (size_t)prod + 1] = m_dec;
     }
   }
+  }
+}
+
+// poly_multiplier / torus_polynomial_mul_r on independent pairs, second form (the one
+// the entry points launch).  Same packing as polymul_kernel (two products per wavefront,
+// one inverse transform), arranged so that only ONE spectrum is parked and no operand
+// load is waited for:
+//   * with P = FFT(d_a + i d_b), Q = FFT(s_a + i s_b) and X'[k] = conj(X[-k]), the
+//     spectrum of product a + i product b is
+//       Z = ((P + P')(Q + Q') - i (P - P')(Q - Q')) / 4 = (W1 + W2') / 4,
+//       W1 = S - i T, W2 = S + i T, S = P Q + P Q', T = P Q - P Q'
+//     (P' Q' and P' Q are the mirror images of P Q and P Q'), so P is needed once per bin,
+//     straight from the accumulation registers, and the two mirror exchanges are those of Q
+//     and of W2;
+//   * the operands of the NEXT pair are copied global -> LDS by the DMA path
+//     (global_load_lds, no registers) while this pair's inverse transform runs; the same
+//     16 KiB of the wavefront's LDS share serve as the second mirror tile in between.
+typedef __attribute__((address_space(3))) void* lds_dma_ptr;
+
+template <int P>
+__device__ __forceinline__ void mirror_store_one(double x, const wfft::MirrorLane& m) {
+  if constexpr (P == 0) wfft::lds_store_f64(m.store_base0, 0, x);
+  else wfft::lds_store_f64(m.store_base, wfft::br5(P) * 256, x);
+}
+
+template <bool ACCUMULATE, bool MARGIN>
+__global__ __launch_bounds__(kBlock, 1) void polymul2_kernel(const int32_t* __restrict__ d,
+                                                             const int32_t* __restrict__ s,
+                                                             const cplx* __restrict__ tables,
+                                                             int32_t* __restrict__ out,
+                                                             double* __restrict__ margin, int B) {
+  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
+  char* lds_tables = lds + kWavesPerBlock * wfft::kWaveBytes;
+  load_tables(lds_tables, tables);
+  const cplx* tE = reinterpret_cast<const cplx*>(lds_tables);
+  const cplx* tw = tE + 1024;
+  const int lane0 = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* wave_tiles = lds + wave * wfft::kWaveBytes;
+  char* stage = wave_tiles + wfft::kExchangeBytes;       // operands in, then the second mirror tile
+  const int stride = gridDim.x * kWavesPerBlock;
+
+  // operands of pair `pair` -> stage: [d_a | d_b | s_a | s_b], 4 KiB each, coefficient order;
+  // a missing second product reads the first one again (its results are not stored)
+  auto fetch = [&](int pair, int lane) WFFT_INLINE {
+    const int ia = 2 * pair, ib = (2 * pair + 1 < B) ? 2 * pair + 1 : ia;
+    const int32_t* src[4] = {d + (size_t)ia * kN, d + (size_t)ib * kN, s + (size_t)ia * kN, s + (size_t)ib * kN};
+    static_for<0, 16>([&](auto ic) WFFT_INLINE {
+      constexpr int i = decltype(ic)::value;
+      __builtin_amdgcn_global_load_lds((const void*)(src[i >> 2] + (i & 3) * 256 + lane * 4),
+                                       (lds_dma_ptr)(stage + i * 1024), 16, 0, 0);
+    });
+  };
+
+  int pair = blockIdx.x * kWavesPerBlock + wave;
+  if (2 * pair < B) fetch(pair, lane0);
+#pragma unroll 1
+  for (; 2 * pair < B; pair += stride) {
+    const int ia = 2 * pair, ib = 2 * pair + 1;
+    const bool has_b = ib < B;
+    // Lane-derived addresses are recomputed in every phase (a handful of instructions)
+    // instead of being kept live, or spilled, across the transforms.
+    auto fresh_lane = [&]() WFFT_INLINE {
+      int l = lane0;
+      asm volatile("" : "+v"(l));
+      return l;
+    };
+    double re[32], im[32];
+    unsigned park[128];      // P, parked in accumulation registers
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the operands have landed
+    {
+      const int lane = fresh_lane(), h = lane >> 5, q = lane & 31;
+      const int32_t* in = reinterpret_cast<const int32_t*>(stage) + q;
+      wfft::chunked_for32<8>([&](auto ic) WFFT_INLINE {
+        constexpr int r = decltype(ic)::value;
+        re[r] = (double)in[32 * r];
+        im[r] = (double)in[kN + 32 * r];
+      });
+      wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+      static_for<0, 32>([&](auto ic) WFFT_INLINE {
+        constexpr int p = decltype(ic)::value;
+        wfft::agpr_put_f64(re[p], park[4 * p + 0], park[4 * p + 1]);
+        wfft::agpr_put_f64(im[p], park[4 * p + 2], park[4 * p + 3]);
+      });
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int lane = fresh_lane(), h = lane >> 5, q = lane & 31;
+      const int32_t* in = reinterpret_cast<const int32_t*>(stage) + q;
+      constexpr double kScale = 1.0 / (4.0 * 2048.0);            // a power of two: exact
+      wfft::chunked_for32<8>([&](auto ic) WFFT_INLINE {
+        constexpr int r = decltype(ic)::value;
+        re[r] = (double)in[2 * kN + 32 * r] * kScale;
+        im[r] = (double)in[3 * kN + 32 * r] * kScale;
+      });
+      wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int lane = fresh_lane(), h = lane >> 5, q = lane & 31;
+      // Q' = (Re Q[-k], -Im Q[-k]): real parts through the first tile into registers, imaginary
+      // parts through the same tile, read bin by bin below
+      const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
+      const wfft::MirrorLane ml2 = wfft::mirror_lane(stage, q, h);
+      double qr[32];           // Re Q', later Im W2
+      wfft::mirror_store(re, ml);
+      static_for<0, 32>([&](auto ic) WFFT_INLINE { qr[decltype(ic)::value] = wfft::mirror_load<decltype(ic)::value>(ml); });
+      wfft::mirror_store(im, ml);
+      wfft::chunked_for32<TFHE_POLYMUL_CHUNK>([&](auto ic) WFFT_INLINE {
+        constexpr int p = decltype(ic)::value;
+        const double qi = -wfft::mirror_load<p>(ml);
+        const double pr = wfft::agpr_get_f64(park[4 * p + 0], park[4 * p + 1]);
+        const double pi = wfft::agpr_get_f64(park[4 * p + 2], park[4 * p + 3]);
+        const double ar = pr * re[p] - pi * im[p], ai = pr * im[p] + pi * re[p];     // A = P Q
+        const double cr = pr * qr[p] - pi * qi, ci = pr * qi + pi * qr[p];           // C = P Q'
+        const double sr = ar + cr, si = ai + ci, tr = ar - cr, ti = ai - ci;
+        re[p] = sr + ti;                                   // W1 = S - i T
+        im[p] = si - tr;
+        mirror_store_one<p>(sr - ti, ml2);                 // Re W2, W2 = S + i T
+        qr[p] = si + tr;                                   // Im W2
+      });
+      wfft::wave_lds_fence();
+      wfft::pipelined_for32<4, double>(
+          [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml2); },
+          [&](auto ic, const double& m) WFFT_INLINE { re[decltype(ic)::value] += m; });
+      // the second tile is free again: start the copy of the next pair's operands
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (2 * (pair + stride) < B) fetch(pair + stride, lane);
+      wfft::mirror_store(qr, ml);
+      wfft::pipelined_for32<4, double>(
+          [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
+          [&](auto ic, const double& m) WFFT_INLINE { im[decltype(ic)::value] -= m; });
+      wfft::wave_lds_fence();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int lane = fresh_lane(), h = lane >> 5, q = lane & 31;
+    // Inverse transform; the second half of the outputs (t >= N) is E - twist*O.
+    wfft::fft1024_inv(re, im, wave_tiles + h * wfft::kHalfBytes, tE, q);
+    wfft::twist_odd_half<true>(re, im, tE, tw, q, h);
+    const int prod = h ? ib : ia;        // half E ends with product a, half O with product b
+    const bool live = h ? has_b : true;
+    // every lane takes part in the half-wave exchange; afterwards re = coefficients t < N,
+    // im = coefficients N + t of this lane's product, t = q + 32 r
+    static_for<0, 32>([&](auto ic) WFFT_INLINE {
+      constexpr int r = decltype(ic)::value;
+      double e = re[r], o = im[r];       // e = (E: Re E | O: Im E), o = (E: Re twO | O: Im twO)
+      wfft::swap_halves(e, o);
+      re[r] = e + o;
+      im[r] = e - o;
+    });
+    if (MARGIN) {
+      Margin mg;
+      static_for<0, 32>([&](auto ic) WFFT_INLINE {
+        constexpr int r = decltype(ic)::value;
+        mg.track(re[r]);
+        if (r < 31 || q < 31) mg.track(im[r]);
+      });
+      for (int off = 16; off >= 1; off >>= 1) {          // largest value of each half-wave
+        mg.all = fmax(mg.all, __shfl_xor(mg.all, off, 64));
+        mg.deciding = fmax(mg.deciding, __shfl_xor(mg.deciding, off, 64));
+      }
+      if (live && q == 0) {
+        margin[2 * (size_t)prod + 0] = mg.all;
+        margin[2 * (size_t)prod + 1] = mg.deciding;
+      }
+    } else if (live) {
+      // one base address per lane; the coefficients of a lane are 32 apart
+      if (ACCUMULATE) {
+        int32_t* dst = out + (size_t)prod * kN + q;
+        int32_t old[32];
+        static_for<0, 32>([&](auto ic) WFFT_INLINE { old[decltype(ic)::value] = dst[32 * decltype(ic)::value]; });
+        static_for<0, 32>([&](auto ic) WFFT_INLINE {
+          constexpr int r = decltype(ic)::value;
+          dst[32 * r] = wadd(old[r], wfft::round_sat_i32(re[r]));
+        });
+      } else {
+        int32_t* lo_p = out + (size_t)prod * (2 * kN - 1) + q;
+        int32_t* hi_p = lo_p + kN;
+        static_for<0, 32>([&](auto ic) WFFT_INLINE {
+          constexpr int r = decltype(ic)::value;
+          lo_p[32 * r] = wfft::round_sat_i32(re[r]);
+          if (r < 31 || q < 31) hi_p[32 * r] = wfft::round_sat_i32(im[r]);      // 2N-1 coefficients
+        });
+      }
+    }
   }
 }
 
@@ -2033,9 +2227,9 @@ int tfhe_hip_polymul_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, 
   const unsigned grid = (unsigned)std::min<size_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock,
                                                    (size_t)ctx->num_cus);
   if (accumulate)
-    hipLaunchKernelGGL((polymul_kernel<true, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (double*)nullptr, (int)B);
+    hipLaunchKernelGGL((TFHE_POLYMUL_KERNEL<true, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (double*)nullptr, (int)B);
   else
-    hipLaunchKernelGGL((polymul_kernel<false, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (double*)nullptr, (int)B);
+    hipLaunchKernelGGL((TFHE_POLYMUL_KERNEL<false, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (double*)nullptr, (int)B);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
@@ -2224,7 +2418,7 @@ int tfhe_hip_polymul_margin_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32
   const size_t pairs = (B + 1) / 2;
   const unsigned grid = (unsigned)std::min<size_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock,
                                                    (size_t)ctx->num_cus);
-  hipLaunchKernelGGL((polymul_kernel<false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s,
+  hipLaunchKernelGGL((TFHE_POLYMUL_KERNEL<false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s,
                      ctx->tables, (int32_t*)nullptr, margin, (int)B);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
