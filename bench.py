@@ -347,8 +347,8 @@ def latency(eng, torch, tensors, K_params_n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="default 3 (polymul: 1000)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 1 (polymul: 200)")
     ap.add_argument("--batch", type=int, default=16384)
     ap.add_argument("--level", type=int, default=80, choices=[80, 128])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -360,6 +360,10 @@ def main():
                     help="synthetic: every key entry uniform (no stage degenerates); reference: "
                          "the structure the crate's generate_keys produces")
     args = ap.parse_args()
+    # a polymul step is ~0.6 ms and the first ~100 ms of a burst run at lower clocks (-6 %)
+    dsteps, dwarm = (1000, 200) if args.workload == "polymul" else (3, 1)
+    args.steps = dsteps if args.steps is None else args.steps
+    args.warmup = dwarm if args.warmup is None else args.warmup
     if args.workload != "nand":
         return side_workload(args)
 

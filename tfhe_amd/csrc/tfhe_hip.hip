@@ -517,7 +517,9 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
     if ((i & 63) == 0) abar64 = (i + lane < args.n) ? bara[i + lane] : 0;
     const int abar = __builtin_amdgcn_readlane(abar64, i & 63);
     if (abar == 0) continue;                                   // bootstrapping.rs:122-126
+    if (i == 0) st.start();
     __syncthreads();                                           // acc of the last iteration is complete
+    TFHE_STAMP(st, 0);
     // t = X^abar (prev + acc) - acc, rows r = wave, wave + W, ... of each polynomial
     // (src/bootstrapping.rs:136-146, src/polynomial.rs:281-313); then prev <- acc.
     {
@@ -538,7 +540,9 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
           keep[e] = a;
         }
       });
+      TFHE_STAMP(st, 1);
       __syncthreads();                                         // tt complete, prev no longer read
+      TFHE_STAMP(st, 2);
       static_for<0, kRows>([&](auto ic) WFFT_INLINE {
         constexpr int e = decltype(ic)::value;
         const int r = wave + W * e;
@@ -558,7 +562,9 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
       re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t.x, decal, BGBIT);
       im[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t.y, decal, BGBIT);
     });
+    TFHE_STAMP(st, 3);
     wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+    TFHE_STAMP(st, 4);
     const cplx* kcol = args.bkfft + ((size_t)i * L * 2 + (size_t)(p * 2 + j)) * 2048 + lane;
     auto load_k = [&](auto ic) WFFT_INLINE { return kcol[decltype(ic)::value * 64]; };
     wfft::Pipe32<4, 3, cplx> kp;
@@ -582,6 +588,7 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
           constexpr int s = decltype(ic)::value;
           im[s] = my * sb + im[s];           // j = 0: Im D_0;  j = 1: Re D_1
         });
+    TFHE_STAMP(st, 5);
     if (j == 0) {
       kp.run(load_k, [&](auto ic, const cplx& k) WFFT_INLINE {
         constexpr int s = decltype(ic)::value;
@@ -597,9 +604,15 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
         im[s] = dr * k.y + di * k.x;
       });
     }
+    TFHE_STAMP(st, 6);
     wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate, []() WFFT_INLINE {});
+    TFHE_STAMP(st, 7);
     }
   }
+#ifdef TFHE_STAMPS
+  if (b == 0 && lane == 0 && (wave == 0 || wave == W - 1))
+    for (int k = 0; k < 8; k++) g_stamps[(wave ? 8 : 0) + k] = st.acc[k];
+#endif
   __syncthreads();
 
   if (HOOK) {
@@ -881,6 +894,8 @@ __global__ __launch_bounds__(kBlock, 1) void polymul2_kernel(const int32_t* __re
 
   int pair = blockIdx.x * kWavesPerBlock + wave;
   if (2 * pair < B) fetch(pair, lane0);
+  StampCtx st;
+  st.start();
 #pragma unroll 1
   for (; 2 * pair < B; pair += stride) {
     const int ia = 2 * pair, ib = 2 * pair + 1;
@@ -894,7 +909,9 @@ __global__ __launch_bounds__(kBlock, 1) void polymul2_kernel(const int32_t* __re
     };
     double re[32], im[32];
     unsigned park[128];      // P, parked in accumulation registers
+    TFHE_STAMP(st, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the operands have landed
+    TFHE_STAMP(st, 1);
     {
       const int lane = fresh_lane(), h = lane >> 5, q = lane & 31;
       const int32_t* in = reinterpret_cast<const int32_t*>(stage) + q;
@@ -903,7 +920,9 @@ __global__ __launch_bounds__(kBlock, 1) void polymul2_kernel(const int32_t* __re
         re[r] = (double)in[32 * r];
         im[r] = (double)in[kN + 32 * r];
       });
+      TFHE_STAMP(st, 2);
       wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+      TFHE_STAMP(st, 3);
       static_for<0, 32>([&](auto ic) WFFT_INLINE {
         constexpr int p = decltype(ic)::value;
         wfft::agpr_put_f64(re[p], park[4 * p + 0], park[4 * p + 1]);
@@ -920,7 +939,9 @@ __global__ __launch_bounds__(kBlock, 1) void polymul2_kernel(const int32_t* __re
         re[r] = (double)in[2 * kN + 32 * r] * kScale;
         im[r] = (double)in[3 * kN + 32 * r] * kScale;
       });
+      TFHE_STAMP(st, 4);
       wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+      TFHE_STAMP(st, 5);
     }
     __builtin_amdgcn_sched_barrier(0);
     {
@@ -933,6 +954,7 @@ __global__ __launch_bounds__(kBlock, 1) void polymul2_kernel(const int32_t* __re
       wfft::mirror_store(re, ml);
       static_for<0, 32>([&](auto ic) WFFT_INLINE { qr[decltype(ic)::value] = wfft::mirror_load<decltype(ic)::value>(ml); });
       wfft::mirror_store(im, ml);
+      TFHE_STAMP(st, 6);
       wfft::chunked_for32<TFHE_POLYMUL_CHUNK>([&](auto ic) WFFT_INLINE {
         constexpr int p = decltype(ic)::value;
         const double qi = -wfft::mirror_load<p>(ml);
@@ -947,6 +969,7 @@ __global__ __launch_bounds__(kBlock, 1) void polymul2_kernel(const int32_t* __re
         qr[p] = si + tr;                                   // Im W2
       });
       wfft::wave_lds_fence();
+      TFHE_STAMP(st, 7);
       wfft::pipelined_for32<4, double>(
           [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml2); },
           [&](auto ic, const double& m) WFFT_INLINE { re[decltype(ic)::value] += m; });
@@ -960,6 +983,7 @@ __global__ __launch_bounds__(kBlock, 1) void polymul2_kernel(const int32_t* __re
       wfft::wave_lds_fence();
     }
     __builtin_amdgcn_sched_barrier(0);
+    TFHE_STAMP(st, 8);
     const int lane = fresh_lane(), h = lane >> 5, q = lane & 31;
     // Inverse transform; the second half of the outputs (t >= N) is E - twist*O.
     wfft::fft1024_inv(re, im, wave_tiles + h * wfft::kHalfBytes, tE, q);
@@ -975,6 +999,7 @@ __global__ __launch_bounds__(kBlock, 1) void polymul2_kernel(const int32_t* __re
       re[r] = e + o;
       im[r] = e - o;
     });
+    TFHE_STAMP(st, 9);
     if (MARGIN) {
       Margin mg;
       static_for<0, 32>([&](auto ic) WFFT_INLINE {
@@ -1010,6 +1035,11 @@ __global__ __launch_bounds__(kBlock, 1) void polymul2_kernel(const int32_t* __re
         });
       }
     }
+    TFHE_STAMP(st, 10);
+#ifdef TFHE_STAMPS
+    if (pair + stride >= B / 2 && blockIdx.x == 7 && lane0 == 0 && wave == 1)
+      for (int k = 0; k < 16; k++) g_stamps[k] = st.acc[k];
+#endif
   }
 }
 

@@ -20,7 +20,7 @@ R = sys.argv[1]
 
 def kernel_key(name):
     for k in ("blind_rotate_split_kernel", "blind_rotate_kernel", "keyswitch_tile_kernel", "keyswitch_kernel",
-              "prologue_kernel", "polymul_kernel", "bk_fft_kernel"):
+              "prologue_kernel", "polymul2_kernel", "polymul_kernel", "bk_fft_kernel"):
         if k in name:
             return k
     return None
@@ -78,7 +78,8 @@ def traffic(fetch_pass, write_pass, kernel):
 t = traffic("pmc_fetch", "pmc_write", "blind_rotate_kernel")
 t["workload"] = "bench.py default: 16384 NAND gates, Bit80"
 json.dump(t, open(f"{P}/{PRE}_traffic.json", "w"), indent=1)
-tp = traffic("pmc_fetch_polymul", "pmc_write_polymul", "polymul_kernel")
+pk = "polymul2_kernel" if "polymul2_kernel" in sums["pmc_fetch_polymul"] else "polymul_kernel"
+tp = traffic("pmc_fetch_polymul", "pmc_write_polymul", pk)
 tp["workload"] = "bench.py --workload polymul: 65536 products"
 json.dump(tp, open(f"{P}/{PRE}_traffic_polymul.json", "w"), indent=1)
 print("traffic GB per launch: blind rotate", t["traffic_bytes_per_launch"] / 1e9, "polymul", tp["traffic_bytes_per_launch"] / 1e9)

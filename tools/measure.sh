@@ -13,7 +13,7 @@ $T 400 python bench.py --steps 10 > $P/bench80.json 2> $P/bench80.err || exit 1
 $T 200 python bench.py --level 128 --steps 5 > $P/bench128.json 2>> $P/bench80.err || exit 1
 $T 200 python bench.py --keys reference --steps 5 $Q > $P/bench80_refkeys.json 2>> $P/bench80.err || exit 1
 $T 300 python bench.py --workload add32 --steps 1 --warmup 0 > $P/add32.json 2>> $P/bench80.err || exit 1
-$T 200 python bench.py --workload polymul --steps 50 --warmup 5 > $P/polymul.json 2>> $P/bench80.err || exit 1
+$T 200 python bench.py --workload polymul > $P/polymul.json 2>> $P/bench80.err || exit 1
 $T 300 rocprofv3 --kernel-trace --stats -d $P/prof -o vm --output-format csv -- python3 bench.py --steps 3 $Q > $P/bench_prof.log 2>&1 || exit 1
 $T 300 rocprofv3 --kernel-trace --stats -d $P/prof_polymul -o vm --output-format csv -- python3 bench.py --workload polymul --steps 20 --warmup 2 > $P/polymul_prof.log 2>&1 || exit 1
 ONE="python3 bench.py --steps 1 --warmup 0 $Q"

@@ -1,34 +1,73 @@
-"""Per-phase clock counts of one wavefront of the throughput blind-rotate kernel.
+"""Per-phase clock counts (s_memtime ticks) of one wavefront of an instrumented kernel.
 
 Needs a library built with -DTFHE_STAMPS (diagnostic build, never the shipped one):
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -mllvm -amdgpu-sched-strategy=max-ilp \
-        -DTFHE_STAMPS -o /tmp/libtfhe_hip_stamps.so tfhe_amd/csrc/tfhe_hip.hip
-  TFHE_HIP_LIB=/tmp/libtfhe_hip_stamps.so python tools/phase_stamps.py
-The stamps serialise the phases, so the shares are indicative only.
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -mllvm -amdgpu-sched-strategy=max-ilp \
+        -DTFHE_STAMPS -o /tmp/stamps.o tfhe_amd/csrc/tfhe_hip.hip
+  hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libstamps.so /tmp/stamps.o tfhe_amd/csrc/host_api.o -ldl -lpthread
+  TFHE_HIP_LIB=/tmp/libstamps.so python tools/phase_stamps.py [batch|split|polymul]
+The stamps are not scheduling barriers: instructions move across them, so the shares of
+neighbouring phases are indicative only (workgroup barriers, as in the split kernel, pin them).
 """
-import ctypes as C, os, sys, json
+import ctypes as C
+import os
+import sys
+
 sys.path.insert(0, os.getcwd())
-import numpy as np, torch
+import torch
+
 import tfhe_amd
-from bench import synthetic_keys, LEVELS
-lv = LEVELS[80]
-params = tfhe_amd.make_params(lv["n"], l=lv["l"], bg_bit=lv["bg_bit"])
+from bench import LEVELS, synthetic_keys
+
+which = sys.argv[1] if len(sys.argv) > 1 else "batch"
 eng = tfhe_amd.Engine(0)
-K = synthetic_keys(80, 5)
-eng.load_keys(params, K["bk"], K["ks_a"], K["ks_b"], K["ks_var"])
-B = 4096
 dev = torch.device("cuda", 0)
-rnd = lambda shape: torch.randint(-2**31, 2**31, shape, dtype=torch.int64, device=dev).to(torch.int32)
-ca_a, ca_b, cb_a, cb_b = rnd((B, 500)), rnd((B,)), rnd((B, 500)), rnd((B,))
-out_a = torch.empty((B, 500), dtype=torch.int32, device=dev); out_b = torch.empty((B,), dtype=torch.int32, device=dev)
-for _ in range(2):
-    eng.gate_dev("nand", ca_a, ca_b, cb_a, cb_b, out_a, out_b)
-torch.cuda.synchronize()
-st = (C.c_ulonglong * 16)()
-eng.lib.tfhe_hip_debug_stamps.argtypes = [C.c_void_p]
-print("rc", eng.lib.tfhe_hip_debug_stamps(C.byref(st)))
-names = {8: "loop/abar", 0: "rotate", 1: "digits", 2: "fwd", 3: "mirror_store", 4: "pointwise", 5: "inv0", 6: "unpark", 7: "inv1"}
-tot = sum(st)
-for k, n in names.items():
-    print(f"{n:14s} {st[k]:12d}  {100.0*st[k]/tot:5.1f}%  per-iter-level {st[k]/1000.0 if k in (8,0) else st[k]/1000.0:9.1f}")
-print("total", tot)
+rnd = lambda shape, lo=-2**31, hi=2**31: torch.randint(lo, hi, shape, dtype=torch.int64, device=dev).to(torch.int32)
+
+
+def stamps():
+    torch.cuda.synchronize()
+    st = (C.c_ulonglong * 16)()
+    eng.lib.tfhe_hip_debug_stamps.argtypes = [C.c_void_p]
+    assert eng.lib.tfhe_hip_debug_stamps(C.byref(st)) == 0
+    return list(st)
+
+
+def show(names, st, per):
+    tot = sum(st[k] for k in names)
+    for k, n in names.items():
+        print(f"  {n:22s} {st[k] / per:9.0f} ticks  {100.0 * st[k] / max(tot, 1):5.1f}%")
+    print(f"  total {tot / per:.0f} ticks per unit")
+
+
+if which == "polymul":
+    B = 65536
+    d, s = rnd((B, 1024), -512, 512), rnd((B, 1024))
+    out = torch.empty((B, 2047), dtype=torch.int32, device=dev)
+    for _ in range(2):
+        eng.polymul_dev(d, s, out)
+    print("polymul2_kernel, per pair of products (32 pairs per wavefront)")
+    show(dict(enumerate(["loop top", "wait for operands", "convert d", "forward d", "park, convert s", "forward s",
+                         "mirror Q", "pointwise", "mirror W2, next fetch", "inverse, twist, swap", "round, store"])),
+         stamps(), 32)
+else:
+    lv = LEVELS[80]
+    params = tfhe_amd.make_params(lv["n"], l=lv["l"], bg_bit=lv["bg_bit"])
+    K = synthetic_keys(80, 5)
+    eng.load_keys(params, K["bk"], K["ks_a"], K["ks_b"], K["ks_var"])
+    B = 4096 if which == "batch" else 1
+    eng.set_blind_rotate_mode(which)
+    ca_a, ca_b, cb_a, cb_b = rnd((B, 500)), rnd((B,)), rnd((B, 500)), rnd((B,))
+    out_a = torch.empty((B, 500), dtype=torch.int32, device=dev)
+    out_b = torch.empty((B,), dtype=torch.int32, device=dev)
+    for _ in range(2):
+        eng.gate_dev("nand", ca_a, ca_b, cb_a, cb_b, out_a, out_b)
+    st = stamps()
+    if which == "batch":
+        # the wavefront that reports has finished three ciphertexts of 500 iterations
+        print("blind_rotate_kernel, per iteration (two levels)")
+        show({8: "loop, abar", 0: "rotate", 1: "digits", 2: "forward", 3: "key prologue, mirror re", 4: "mirror, product 0",
+              5: "inverse 0", 6: "unpark, product 1", 7: "inverse 1"}, st, 1500)
+    else:
+        print("blind_rotate_split_kernel (one ciphertext), wavefront 0, per iteration")
+        show(dict(enumerate(["barrier (acc complete)", "rotate", "barrier (tt complete)", "prev, digits", "forward",
+                             "mirror (key loads issued)", "product (key wait)", "inverse, atomics"])), st, 500)

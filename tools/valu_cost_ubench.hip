@@ -1,0 +1,70 @@
+// Cost of one vector instruction for ONE wavefront per SIMD, by instruction type, in s_memtime
+// ticks, in nanoseconds (HIP events) and in ticks of the 100 MHz wall clock; one workgroup and
+// one workgroup per compute unit.  hipcc --offload-arch=gfx950 -O3 -o ubench tools/valu_cost_ubench.hip
+// Measured on MI355X: 1.88-2.12 ns (one compute unit busy) and 1.90-2.27 ns (all busy) per
+// instruction whatever its type (v_mov_b32 1.96, v_add_f32 1.88, v_add_f64 2.07, v_fma_f64 2.12,
+// v_accvgpr_write_b32 2.25); four clocks of 2.4 GHz would be 1.67 ns.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+template <int OP>
+__global__ __launch_bounds__(256, 1) void k(unsigned long long* out, double seed, int iters) {
+  double x[16]; float f[16]; unsigned a[16];
+  for (int i = 0; i < 16; i++) { x[i] = seed + i + threadIdx.x; f[i] = (float)x[i]; a[i] = i; }
+  double w = 1.0000001, z = 0.5; float wf = 1.0001f, zf = 0.5f;
+  unsigned long long t0 = clock64();
+  unsigned long long r0 = wall_clock64();
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int rep = 0; rep < 4; rep++) {
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        if (OP == 0) asm volatile("v_add_f64 %0, %0, %1" : "+v"(x[c]) : "v"(z));
+        if (OP == 1) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(x[c]) : "v"(w), "v"(z));
+        if (OP == 2) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[c]) : "v"(zf));
+        if (OP == 3) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[c]) : "v"(wf), "v"(zf));
+        if (OP == 4) asm volatile("v_mov_b32 %0, %1" : "+v"(a[c]) : "v"(a[(c + 1) & 15]));
+        if (OP == 5) asm volatile("v_accvgpr_write_b32 a[%1], %0" : : "v"(a[c]), "n"(c));
+        if (OP == 6) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(x[c]) : "v"(w));
+        if (OP == 7) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(x[c]) : "v"(w));
+        if (OP == 8) asm volatile("v_fma_f64 %0, %0, 0.5, 1.0" : "+v"(x[c]));
+        if (OP == 9) asm volatile("v_add_f64 %0, %0, 1.0" : "+v"(x[c]));
+      }
+    }
+  }
+  unsigned long long t1 = clock64();
+  unsigned long long r1 = wall_clock64();
+  if (threadIdx.x == 32 && blockIdx.x == 0) { out[0] = t1 - t0; out[2] = r1 - r0; }
+  double s = 0; for (int i = 0; i < 16; i++) s += x[i] + f[i] + a[i];
+  if (s == 12345.678) out[1] = 1;
+}
+template <int OP> void run(const char* name, unsigned long long* d, int blocks) {
+  unsigned long long h[3];
+  const int iters = 20000;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  k<OP><<<blocks, 256>>>(d, 1.0, iters);
+  hipEventRecord(e0);
+  k<OP><<<blocks, 256>>>(d, 1.0, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+  const double n = (double)iters * 64;
+  printf("%-34s blocks %3d: %5.2f clock64 ticks, %6.3f ns (events), %6.3f wall_clock64 ticks per instruction\n", name, blocks,
+         h[0] / n, ms * 1e6 / n, h[2] / n);
+}
+int main() {
+  unsigned long long* d; hipMalloc(&d, 32);
+  for (int blocks : {1, 256}) {
+    run<0>("v_add_f64 v,v,v", d, blocks);
+    run<9>("v_add_f64 v,v,const", d, blocks);
+    run<6>("v_mul_f64 v,v,v", d, blocks);
+    run<1>("v_fma_f64 v,v,v,v", d, blocks);
+    run<7>("v_fma_f64 v,v,v,v(same)", d, blocks);
+    run<8>("v_fma_f64 v,v,const,const", d, blocks);
+    run<2>("v_add_f32", d, blocks);
+    run<3>("v_fma_f32", d, blocks);
+    run<4>("v_mov_b32", d, blocks);
+    run<5>("v_accvgpr_write_b32", d, blocks);
+  }
+  return 0;
+}
