@@ -11,7 +11,12 @@ uniform), so no stage degenerates to zeros; the kernels are data independent.
   python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--level 80|128]
                   [--workload nand|add32|polymul]
 
---workload nand (default) is the headline metric.  add32 times the level-batched
+--workload nand (default) is the headline metric; its line also carries the
+blind-rotate roofline (live HIP-event durations; traffic from the committed
+counter pass), p50 single-gate latency, a check of one timed output against the
+CPU oracle, the same measurements on the crate's default parameters (Bit128,
+"bit128" block, --no-bit128 skips it) and the CPU baseline (the restated
+reference algorithm on every CPU this job may use).  add32 times the level-batched
 ripple-carry adder (circuits::add on 32-bit operands, 160 gates per instance,
 --batch instances per GPU per step); polymul times isolated polynomial products
 (--batch products per step).  Each prints its own single JSON line.

@@ -15,7 +15,7 @@ $T 200 python bench.py --keys reference --steps 5 $Q > $P/bench80_refkeys.json 2
 $T 300 python bench.py --workload add32 --steps 1 --warmup 0 > $P/add32.json 2>> $P/bench80.err || exit 1
 $T 200 python bench.py --workload polymul > $P/polymul.json 2>> $P/bench80.err || exit 1
 $T 300 rocprofv3 --kernel-trace --stats -d $P/prof -o vm --output-format csv -- python3 bench.py --steps 3 $Q > $P/bench_prof.log 2>&1 || exit 1
-$T 300 rocprofv3 --kernel-trace --stats -d $P/prof_polymul -o vm --output-format csv -- python3 bench.py --workload polymul --steps 20 --warmup 2 > $P/polymul_prof.log 2>&1 || exit 1
+$T 300 rocprofv3 --kernel-trace --stats -d $P/prof_polymul -o vm --output-format csv -- python3 bench.py --workload polymul > $P/polymul_prof.log 2>&1 || exit 1
 ONE="python3 bench.py --steps 1 --warmup 0 $Q"
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $P/pmc_fetch -o vm --output-format csv -- $ONE > $P/pmc_fetch.log 2>&1 || exit 1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $P/pmc_write -o vm --output-format csv -- $ONE > $P/pmc_write.log 2>&1 || exit 1
@@ -24,6 +24,8 @@ timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST
 PM="python3 bench.py --workload polymul --steps 1 --warmup 0"
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $P/pmc_fetch_polymul -o vm --output-format csv -- $PM > $P/pmc_fetch_polymul.log 2>&1 || exit 1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $P/pmc_write_polymul -o vm --output-format csv -- $PM > $P/pmc_write_polymul.log 2>&1 || exit 1
+# cost of one vector instruction at one wavefront per SIMD
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o /tmp/valu_cost_ubench tools/valu_cost_ubench.hip 2> /dev/null && $T 60 /tmp/valu_cost_ubench > $P/valu_cost_ubench.txt || exit 1
 # the CSVs of the counter passes are large; keep per-kernel sums only
 python3 tools/collect_profiles.py $P --sums-only
 rm -rf $P/pmc_*/vm
