@@ -259,9 +259,12 @@ def side_workload(args):
         dist.destroy_process_group()
 
 
-def time_nand(eng, torch, dist, dev, world, rank, level, K, B, steps, warmup, check=True):
-    """Times `steps` batches of B NAND gates on the loaded keys; returns the measurements of
-    this rank (max over ranks for the elapsed time) and checks one timed output."""
+def time_nand(eng, torch, dist, dev, world, rank, level, K, B, steps, warmup, check=True, chunk=None,
+              total=None):
+    """Times `steps` batches of B NAND gates on the loaded keys (each batch in launches of at
+    most `chunk` gates); returns the measurements of this rank (max over ranks for the elapsed
+    time) and checks one timed output.  total: gates of all ranks per step (default B * world)."""
+    chunk = chunk or B
     lv = LEVELS[level]
     n = lv["n"]
     g = torch.Generator(device=dev)
@@ -276,7 +279,9 @@ def time_nand(eng, torch, dist, dev, world, rank, level, K, B, steps, warmup, ch
     out_b = torch.empty((B,), dtype=torch.int32, device=dev)
 
     def step():
-        eng.gate_dev("nand", ca_a, ca_b, cb_a, cb_b, out_a, out_b)
+        for c in range(0, B, chunk):
+            e = min(B, c + chunk)
+            eng.gate_dev("nand", ca_a[c:e], ca_b[c:e], cb_a[c:e], cb_b[c:e], out_a[c:e], out_b[c:e])
 
     def fence():
         torch.cuda.synchronize()
@@ -303,11 +308,13 @@ def time_nand(eng, torch, dist, dev, world, rank, level, K, B, steps, warmup, ch
     br_ms, br_cnt = prof["blind_rotate"]
     ks_ms, ks_cnt = prof["keyswitch"]
     br_avg_s = br_ms / max(br_cnt, 1) / 1e3
-    flop_launch = flop_per_iteration(lv["l"]) * lv["n"] * B
+    # algorithmic flop of the timed launches over their summed duration
+    flop_launch = flop_per_iteration(lv["l"]) * lv["n"] * B * steps / max(br_cnt, 1)
     achieved = flop_launch / br_avg_s / 1e12 if br_avg_s > 0 else 0.0
-    traffic, traffic_from = measured_traffic(level, B)
+    traffic, traffic_from = measured_traffic(level, chunk)
     res = {
-        "value": B * world * steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
+        "value": (total if total is not None else B * world) * steps / elapsed,
+        "ms_per_step": elapsed / steps * 1e3,
         "roofline": {"bound": "fp64_valu", "kernel": "blind_rotate_kernel",
                      "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
@@ -360,6 +367,9 @@ def main():
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-bit128", action="store_true",
                     help="skip the Bit128 block that the default Bit80 run adds")
+    ap.add_argument("--total-gates", type=int, default=None,
+                    help="strong scaling: this many gates per step over ALL ranks (contiguous shards, "
+                         "launches of --batch gates); BASELINE config 4 is --total-gates 1048576")
     ap.add_argument("--workload", default="nand", choices=["nand", "add32", "polymul"])
     ap.add_argument("--keys", default="synthetic", choices=["synthetic", "reference"],
                     help="synthetic: every key entry uniform (no stage degenerates); reference: "
@@ -407,7 +417,14 @@ def main():
     B = args.batch
     lv = LEVELS[args.level]
     K = load(args.level)
-    main_res, tensors = time_nand(eng, torch, dist, dev, world, rank, args.level, K, B, args.steps, args.warmup)
+    if args.total_gates:
+        from tfhe_amd import parallel
+        lo, hi = parallel.shard_bounds(args.total_gates, rank, world)
+        main_res, tensors = time_nand(eng, torch, dist, dev, world, rank, args.level, K, hi - lo, args.steps,
+                                      args.warmup, chunk=B, total=args.total_gates)
+    else:
+        main_res, tensors = time_nand(eng, torch, dist, dev, world, rank, args.level, K, B, args.steps,
+                                      args.warmup)
     p50 = p50_host = None
     if rank == 0 and not args.no_latency:
         p50, p50_host = latency(eng, torch, tensors, lv["n"])
@@ -428,11 +445,14 @@ def main():
             "metric": "bootstrapped NAND gates/sec (node, default params)",
             "value": main_res["value"], "unit": "gates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"batched bootstrapped NAND, {B} gates per GPU per step, "
+            "higher_is_better": True, "scaling": "strong" if args.total_gates else "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": (f"{args.total_gates} bootstrapped NAND gates per step in contiguous shards "
+                                    f"over {world} GPU(s), launches of {B} gates, " if args.total_gates else
+                                    f"batched bootstrapped NAND, {B} gates per GPU per step, ") +
                                    f"Bit{args.level} (n={lv['n']}, N=1024, k=1, l={lv['l']}, "
                                    f"Bg=2^{lv['bg_bit']}, ks t=8 base=4), {args.keys} keys resident in HBM",
+                       "total_gates": args.total_gates,
                        "batch_per_gpu": B, "security_level": args.level,
                        "parallelism": f"batch sharded over {world} GPU(s), keys replicated"},
             "p50_single_gate_latency_ms": p50,

@@ -39,9 +39,11 @@ struct StampCtx {
   unsigned long long last = 0;
   __device__ __forceinline__ void start() { last = clock64(); }
   __device__ __forceinline__ void mark(int k) {
+    __builtin_amdgcn_sched_barrier(0);       // instructions do not move across a stamp
     const unsigned long long t = clock64();
     acc[k] += t - last;
     last = t;
+    __builtin_amdgcn_sched_barrier(0);
   }
 };
 #define TFHE_STAMP(ctx, k) (ctx).mark(k)
@@ -469,11 +471,12 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
 // the registers.
 //
 // LDS: per wavefront the FFT exchange area, then per workgroup prev [2][N],
-// acc [2][N], tt [N][2] (int32), then the twiddle tables.
+// acc [2][N], tt [N][2] and tt with its two polynomials swapped [N][2] (int32),
+// then the twiddle tables.
 // ---------------------------------------------------------------------------
 template <int W>
 constexpr int split_lds_bytes() {
-  return W * wfft::kExchangeBytes + 3 * 2 * kN * 4 + kTableBytes;
+  return W * wfft::kExchangeBytes + 4 * 2 * kN * 4 + kTableBytes;
 }
 
 template <int L, int BGBIT, bool HOOK, int CPW>
@@ -485,7 +488,8 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
   int32_t* prevL = reinterpret_cast<int32_t*>(shared);
   int32_t* accL = prevL + 2 * kN;
   int32_t* ttL = accL + 2 * kN;
-  char* lds_tables = shared + 3 * 2 * kN * 4;
+  int32_t* ttS = ttL + 2 * kN;          // (polynomial 1, polynomial 0) per coefficient
+  char* lds_tables = shared + 4 * 2 * kN * 4;
   load_tables(lds_tables, args.tables);
   const cplx* tE = reinterpret_cast<const cplx*>(lds_tables);
   const cplx* tw = tE + 1024;
@@ -536,7 +540,9 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
           const int32_t v = wadd(prevL[h * kN + src], accL[h * kN + src]);
           const int32_t a = accL[h * kN + n];
           const int32_t x = ((base < -32 * r) != mp.cycle) ? wneg(v) : v;
-          ttL[2 * n + h] = (int32_t)((uint32_t)wsub(x, a) ^ kMaskTt);
+          const int32_t tv = (int32_t)((uint32_t)wsub(x, a) ^ kMaskTt);
+          ttL[2 * n + h] = tv;
+          if constexpr (CPW == 1) ttS[2 * n + 1 - h] = tv;
           keep[e] = a;
         }
       });
@@ -554,11 +560,15 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
       level_product<BGBIT>(p, tt, args.bkfft + ((size_t)i * L + p) * 2 * 2048, wave_tiles, tE, tw, lane,
                            accumulate, st);
     } else {
-    // this wavefront's (level, column) product
+    // this wavefront's (level, column) product.  Column 1 reads the sample with its two
+    // polynomials swapped, c' = d_{p,1} + i d_{p,0}: the spectrum it needs, that of
+    // d_{p,1}, is then C' + Ct' (Ct[k] = conj(C[-k])), the expression column 0 uses
+    // for d_{p,0}, so all four wavefronts run the same code.
+    const char* ttj = reinterpret_cast<const char*>(j ? ttS : ttL) + q * 8;
     double re[32], im[32];
     static_for<0, 32>([&](auto ic) WFFT_INLINE {
       constexpr int r = decltype(ic)::value;
-      const int2 t = *reinterpret_cast<const int2*>(tt + r * 256);
+      const int2 t = *reinterpret_cast<const int2*>(ttj + r * 256);
       re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t.x, decal, BGBIT);
       im[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t.y, decal, BGBIT);
     });
@@ -569,41 +579,23 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
     auto load_k = [&](auto ic) WFFT_INLINE { return kcol[decltype(ic)::value * 64]; };
     wfft::Pipe32<4, 3, cplx> kp;
     kp.prologue(load_k);
-    // D_0 = C + Ct (column 0) or D_1 = -i (C - Ct) (column 1), Ct[k] = conj(C[-k]):
-    //   j = 0: Re = re + cx, Im = im - my;   j = 1: Re = im + my, Im = cx - re
-    // with cx, my the real and imaginary part of C[-k].
-    const double sa = j ? -1.0 : 1.0, sb = j ? 1.0 : -1.0;
+    // D = C + Ct: Re = re + cx, Im = im - my with (cx, my) = C[-k]
     const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
     wfft::mirror_store(re, ml);
     wfft::pipelined_for32<4, double>(
         [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
-        [&](auto ic, const double& cx) WFFT_INLINE {
-          constexpr int s = decltype(ic)::value;
-          re[s] = re[s] * sa + cx;           // j = 0: Re D_0;  j = 1: Im D_1
-        });
+        [&](auto ic, const double& cx) WFFT_INLINE { re[decltype(ic)::value] += cx; });
     wfft::mirror_store(im, ml);
     wfft::pipelined_for32<4, double>(
         [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
-        [&](auto ic, const double& my) WFFT_INLINE {
-          constexpr int s = decltype(ic)::value;
-          im[s] = my * sb + im[s];           // j = 0: Im D_0;  j = 1: Re D_1
-        });
+        [&](auto ic, const double& my) WFFT_INLINE { im[decltype(ic)::value] -= my; });
     TFHE_STAMP(st, 5);
-    if (j == 0) {
-      kp.run(load_k, [&](auto ic, const cplx& k) WFFT_INLINE {
-        constexpr int s = decltype(ic)::value;
-        const double dr = re[s], di = im[s];
-        re[s] = dr * k.x - di * k.y;
-        im[s] = dr * k.y + di * k.x;
-      });
-    } else {
-      kp.run(load_k, [&](auto ic, const cplx& k) WFFT_INLINE {
-        constexpr int s = decltype(ic)::value;
-        const double dr = im[s], di = re[s];
-        re[s] = dr * k.x - di * k.y;
-        im[s] = dr * k.y + di * k.x;
-      });
-    }
+    kp.run(load_k, [&](auto ic, const cplx& k) WFFT_INLINE {
+      constexpr int s = decltype(ic)::value;
+      const double dr = re[s], di = im[s];
+      re[s] = dr * k.x - di * k.y;
+      im[s] = dr * k.y + di * k.x;
+    });
     TFHE_STAMP(st, 6);
     wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate, []() WFFT_INLINE {});
     TFHE_STAMP(st, 7);
