@@ -892,20 +892,22 @@ __global__ __launch_bounds__(kBlock, 1) void polymul2_kernel(const int32_t* __re
   for (; 2 * pair < B; pair += stride) {
     const int ia = 2 * pair, ib = 2 * pair + 1;
     const bool has_b = ib < B;
-    // Lane-derived addresses are recomputed in every phase (a handful of instructions)
-    // instead of being kept live, or spilled, across the transforms.
+    // Lane-derived addresses are recomputed per phase (a handful of instructions; the two
+    // forward transforms share one set) instead of being kept live, or spilled, across the loop.
     auto fresh_lane = [&]() WFFT_INLINE {
       int l = lane0;
       asm volatile("" : "+v"(l));
       return l;
     };
     double re[32], im[32];
+    int lane_keep = 0;       // the lane index the two forward transforms derive their addresses from
     unsigned park[128];      // P, parked in accumulation registers
     TFHE_STAMP(st, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the operands have landed
     TFHE_STAMP(st, 1);
     {
       const int lane = fresh_lane(), h = lane >> 5, q = lane & 31;
+      lane_keep = lane;
       const int32_t* in = reinterpret_cast<const int32_t*>(stage) + q;
       wfft::chunked_for32<8>([&](auto ic) WFFT_INLINE {
         constexpr int r = decltype(ic)::value;
@@ -923,7 +925,7 @@ __global__ __launch_bounds__(kBlock, 1) void polymul2_kernel(const int32_t* __re
     }
     __builtin_amdgcn_sched_barrier(0);
     {
-      const int lane = fresh_lane(), h = lane >> 5, q = lane & 31;
+      const int lane = lane_keep, h = lane >> 5, q = lane & 31;      // as in the first transform
       const int32_t* in = reinterpret_cast<const int32_t*>(stage) + q;
       constexpr double kScale = 1.0 / (4.0 * 2048.0);            // a power of two: exact
       wfft::chunked_for32<8>([&](auto ic) WFFT_INLINE {
@@ -938,40 +940,65 @@ __global__ __launch_bounds__(kBlock, 1) void polymul2_kernel(const int32_t* __re
     __builtin_amdgcn_sched_barrier(0);
     {
       const int lane = fresh_lane(), h = lane >> 5, q = lane & 31;
-      // Q' = (Re Q[-k], -Im Q[-k]): real parts through the first tile into registers, imaginary
-      // parts through the same tile, read bin by bin below
+      // Q' = (Re Q[-k], -Im Q[-k]): real parts through the first tile, imaginary parts through
+      // the second.  Step m handles the two bins of a lane whose rows are m and 31 - m: it
+      // reads their mirror values (rows 31 - m and m) and leaves W2 of both bins where the
+      // Q values stood, so that W2 never occupies registers.  The stores run one step late:
+      // lane 0 of half E, its own mirror lane, keeps its values one row lower, and its row
+      // 30 - m is read in step m + 1.  (A wavefront's LDS operations run in program order.)
       const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
       const wfft::MirrorLane ml2 = wfft::mirror_lane(stage, q, h);
-      double qr[32];           // Re Q', later Im W2
       wfft::mirror_store(re, ml);
-      static_for<0, 32>([&](auto ic) WFFT_INLINE { qr[decltype(ic)::value] = wfft::mirror_load<decltype(ic)::value>(ml); });
-      wfft::mirror_store(im, ml);
+      wfft::mirror_store(im, ml2);
       TFHE_STAMP(st, 6);
-      wfft::chunked_for32<TFHE_POLYMUL_CHUNK>([&](auto ic) WFFT_INLINE {
-        constexpr int p = decltype(ic)::value;
-        const double qi = -wfft::mirror_load<p>(ml);
+      double w2r[32], w2i[32];      // W2 = S + i T of the bins of the step before
+      auto point = [&](auto pc, double qr, double qi) WFFT_INLINE {
+        constexpr int p = decltype(pc)::value;
         const double pr = wfft::agpr_get_f64(park[4 * p + 0], park[4 * p + 1]);
         const double pi = wfft::agpr_get_f64(park[4 * p + 2], park[4 * p + 3]);
         const double ar = pr * re[p] - pi * im[p], ai = pr * im[p] + pi * re[p];     // A = P Q
-        const double cr = pr * qr[p] - pi * qi, ci = pr * qi + pi * qr[p];           // C = P Q'
+        const double cr = pr * qr - pi * qi, ci = pr * qi + pi * qr;                 // C = P Q'
         const double sr = ar + cr, si = ai + ci, tr = ar - cr, ti = ai - ci;
-        re[p] = sr + ti;                                   // W1 = S - i T
-        im[p] = si - tr;
-        mirror_store_one<p>(sr - ti, ml2);                 // Re W2, W2 = S + i T
-        qr[p] = si + tr;                                   // Im W2
+        double w1r = sr + ti, w1i = si - tr;               // W1 = S - i T
+        // computed here, not where it is next used: keeps S and T from staying alive instead
+        asm volatile("" : "+v"(w1r), "+v"(w1i));
+        re[p] = w1r;
+        im[p] = w1i;
+        w2r[p] = sr - ti;
+        w2i[p] = si + tr;
+      };
+      auto put = [&](auto pc) WFFT_INLINE {
+        constexpr int p = decltype(pc)::value;
+        mirror_store_one<p>(w2r[p], ml);
+        mirror_store_one<p>(w2i[p], ml2);
+      };
+      static_for<0, 16>([&](auto mc) WFFT_INLINE {
+        constexpr int m = decltype(mc)::value;
+        constexpr int pa = wfft::br5(m), pb = wfft::br5(31 - m);
+        const double qra = wfft::mirror_load<pa>(ml), qia = -wfft::mirror_load<pa>(ml2);
+        const double qrb = wfft::mirror_load<pb>(ml), qib = -wfft::mirror_load<pb>(ml2);
+        if constexpr (m > 0) {
+          put(std::integral_constant<int, wfft::br5(m - 1)>{});
+          put(std::integral_constant<int, wfft::br5(32 - m)>{});
+        }
+        point(std::integral_constant<int, pa>{}, qra, qia);
+        point(std::integral_constant<int, pb>{}, qrb, qib);
+        __builtin_amdgcn_sched_barrier(0);
       });
+      put(std::integral_constant<int, wfft::br5(15)>{});
+      put(std::integral_constant<int, wfft::br5(16)>{});
       wfft::wave_lds_fence();
       TFHE_STAMP(st, 7);
+      // Z = (W1 + W2') / 4 (the factor is in Q), W2' = (Re W2[-k], -Im W2[-k])
+      wfft::pipelined_for32<4, double>(
+          [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
+          [&](auto ic, const double& m) WFFT_INLINE { re[decltype(ic)::value] += m; });
       wfft::pipelined_for32<4, double>(
           [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml2); },
-          [&](auto ic, const double& m) WFFT_INLINE { re[decltype(ic)::value] += m; });
+          [&](auto ic, const double& m) WFFT_INLINE { im[decltype(ic)::value] -= m; });
       // the second tile is free again: start the copy of the next pair's operands
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (2 * (pair + stride) < B) fetch(pair + stride, lane);
-      wfft::mirror_store(qr, ml);
-      wfft::pipelined_for32<4, double>(
-          [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
-          [&](auto ic, const double& m) WFFT_INLINE { im[decltype(ic)::value] -= m; });
       wfft::wave_lds_fence();
     }
     __builtin_amdgcn_sched_barrier(0);
