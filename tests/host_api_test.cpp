@@ -123,6 +123,41 @@ int main() {
     try { (void)nand(bad, bad, ck); } catch (const std::runtime_error&) { threw = true; }
     CHECK(threw, "size mismatch not reported");
   }
+  // keys drawn on the GPU: same structure, reproducible from the seed, gates match the oracle
+  // run on the exported key material; key file and two-worker context give the same results
+  // (bit-exact parity is the check: with the key structure the crate generates a bootstrapped
+  // gate does not decrypt to its truth table, which is why the crate's CI runs with the
+  // `bootstrapping` feature off, tests/bootstrapping_tests.rs:136-198)
+  {
+    uint8_t seed[32];
+    for (int i = 0; i < 32; i++) seed[i] = (uint8_t)(7 * i + 3);
+    auto [gsk, gck] = generate_keys_gpu(params, seed);
+    auto [gsk2, gck2] = generate_keys_gpu(params, seed);
+    CHECK(gsk.lwe_key == gsk2.lwe_key && gck.bk == gck2.bk && gck.ks_a == gck2.ks_a && gck.ks_b == gck2.ks_b,
+          "generate_keys_gpu: a seed does not reproduce its keys");
+    for (int i = 0; i < P.n; i++) {
+      const int32_t* s = gck.bk.data() + i * sample;
+      for (size_t x = 2 * 2 * (size_t)P.N; x < sample; x++) CHECK(s[x] == 0, "gpu keys: row >= 1 not zero");
+      CHECK(s[1 * P.N] == gsk.lwe_key[i] * P.l, "gpu keys: b-poly coefficient 0");
+    }
+    CloudKey from_file = CloudKey::from_bytes(params, gck.to_bytes());
+    CloudKey two = gck;                // same key material on a context of two workers (one GPU twice)
+    two.upload(std::vector<int>{0, 0});
+    std::vector<LweSample> va, vb;
+    for (int bits = 0; bits < 4; bits++) { va.push_back(encrypt(bits & 1, gsk)); vb.push_back(encrypt(bits & 2, gsk)); }
+    const std::vector<LweSample> many = nand(va, vb, two);
+    for (int bits = 0; bits < 4; bits++) {
+      const LweSample &a = va[bits], &b = vb[bits];
+      const LweSample got = nand(a, b, gck);
+      orc_gate(&P, ORC_GATE_NAND, gck.bk.data(), nullptr, gck.ks_a.data(), gck.ks_b.data(), gck.ks_var.data(),
+               a.coefficients.data(), a.b, a.current_variance, b.coefficients.data(), b.b,
+               b.current_variance, a.coefficients.data(), 0, 0.0, oa.data(), &ob, &ov, ORC_MUL_FFT, nullptr);
+      CHECK(got.coefficients == oa && got.b == ob && got.current_variance == ov, "gpu keys: nand vs oracle %d", bits);
+      const LweSample f = nand(a, b, from_file);
+      CHECK(f.coefficients == got.coefficients && f.b == got.b, "key file: nand %d", bits);
+      CHECK(many[bits].coefficients == got.coefficients && many[bits].b == got.b, "two workers: nand %d", bits);
+    }
+  }
   std::printf(failures ? "host_api_test: %d FAILURES\n" : "host_api_test: ok\n", failures);
   return failures ? 1 : 0;
 }

@@ -126,6 +126,11 @@ struct Device {
     if (tfhe_hip_create(&ctx, device) != 0)
       throw std::runtime_error("tfhe_hip_create failed: no usable GPU " + std::to_string(device));
   }
+  // one context over several GPUs: batches are split over them, keys replicated once
+  explicit Device(const std::vector<int>& devices) {
+    if (tfhe_hip_create_multi(&ctx, devices.data(), (int)devices.size()) != 0)
+      throw std::runtime_error("tfhe_hip_create_multi failed");
+  }
   ~Device() { tfhe_hip_destroy(ctx); }
   Device(const Device&) = delete;
   Device& operator=(const Device&) = delete;
@@ -154,6 +159,36 @@ struct CloudKey {
   // Uploads the key material to GPU `device_index` (done by generate_keys).
   void upload(int device_index = 0) {
     device = std::make_shared<detail::Device>(device_index);
+    load();
+  }
+  // Uploads it to several GPUs: every batched call is then split over them.
+  void upload(const std::vector<int>& devices) {
+    device = std::make_shared<detail::Device>(devices);
+    load();
+  }
+  // The key file of tfhe_hip_key_file_pack (the crate derives Serialize for CloudKey,
+  // src/lwe.rs:247-251, without fixing a byte format).
+  std::vector<unsigned char> to_bytes() const {
+    tfhe_hip_params hp = hip_params();
+    size_t bytes = 0;
+    if (tfhe_hip_key_file_size(&hp, 1, &bytes) != 0) throw std::runtime_error("tfhe_hip_key_file_size failed");
+    std::vector<unsigned char> out(bytes);
+    if (tfhe_hip_key_file_pack(&hp, bk.data(), ks_a.data(), ks_b.data(), ks_var.data(), out.data(), bytes) != 0)
+      throw std::runtime_error("tfhe_hip_key_file_pack failed");
+    return out;
+  }
+  // A CloudKey for gates only (the flat key arrays stay empty) from a key file image.
+  static CloudKey from_bytes(const Parameters& params, const std::vector<unsigned char>& image,
+                             int device_index = 0) {
+    CloudKey ck;
+    ck.params = params;
+    ck.device = std::make_shared<detail::Device>(device_index);
+    ck.device->check(tfhe_hip_load_keys_blob(ck.device->ctx, image.data(), image.size()));
+    return ck;
+  }
+
+ private:
+  void load() {
     tfhe_hip_params hp = hip_params();
     device->check(tfhe_hip_load_keys(device->ctx, &hp, bk.data(), ks_a.data(), ks_b.data(), ks_var.data()));
   }
@@ -230,6 +265,31 @@ inline std::pair<SecretKey, CloudKey> generate_keys(const Parameters& params, in
       }
   }
   ck.upload(device_index);
+  return {std::move(sk), std::move(ck)};
+}
+
+// generate_keys with the randomness drawn on the GPU (tfhe_hip_generate_keys): the same key
+// structure, every value a function of `seed` (32 bytes, the ChaCha20 key), so a seed
+// reproduces its keys.  Use operating-system entropy for real keys.
+inline std::pair<SecretKey, CloudKey> generate_keys_gpu(const Parameters& params, const uint8_t seed[32],
+                                                        int device_index = 0) {
+  const int32_t n = params.in_out_params.n, N = params.tgsw_params.tlwe_params.n;
+  const int32_t k = params.tgsw_params.tlwe_params.k, l = params.tgsw_params.l;
+  const size_t rows = (size_t)n * params.ks_t * ((size_t)1 << params.ks_base_bit);
+  SecretKey sk{params, std::vector<int32_t>(n)};
+  std::vector<int32_t> tlwe_key((size_t)(k + 1) * N);
+  CloudKey ck;
+  ck.params = params;
+  ck.bk.resize((size_t)n * l * (k + 1) * (k + 1) * N);
+  ck.ks_a.resize(rows * n);
+  ck.ks_b.resize(rows);
+  ck.ks_var.resize(rows);
+  ck.device = std::make_shared<detail::Device>(device_index);
+  tfhe_hip_params hp = ck.hip_params();
+  ck.device->check(tfhe_hip_generate_keys(ck.device->ctx, &hp, params.in_out_params.alpha_min,
+                                          params.tgsw_params.tlwe_params.alpha_min, seed, sk.lwe_key.data(),
+                                          tlwe_key.data(), ck.bk.data(), ck.ks_a.data(), ck.ks_b.data(),
+                                          ck.ks_var.data()));
   return {std::move(sk), std::move(ck)};
 }
 
