@@ -160,6 +160,33 @@ def oracle_check(level, K, ca_a, ca_b, cb_a, cb_b, out_a, out_b, index):
     return bool((out_a[index].cpu().numpy() == wa).all() and int(out_b[index]) == wb)
 
 
+def progress(msg):
+    """Progress lines go to stderr; stdout carries the one JSON line."""
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def init_ranks(torch, dist):
+    """One process per GPU: reads RANK / LOCAL_RANK / WORLD_SIZE, selects the GPU, joins the
+    process group (RCCL).  Returns (world, rank, device).
+    Rehearsal of the multi-rank path on a box with fewer GPUs than ranks: TFHE_BENCH_REHEARSE=1
+    puts every rank on GPU 0 and uses gloo (RCCL refuses two ranks on one GPU); the numbers of
+    such a run mean nothing, it only exercises the code path."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rehearse = os.environ.get("TFHE_BENCH_REHEARSE") == "1"
+    gpu = 0 if (rehearse or world == 1) else local_rank
+    torch.cuda.set_device(gpu)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", gpu))
+    return world, rank, torch.device("cuda", gpu)
+
+
 def side_workload(args):
     """Secondary workloads (not the headline metric): one JSON line each."""
     import torch
@@ -167,15 +194,7 @@ def side_workload(args):
 
     import tfhe_amd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
+    world, rank, dev = init_ranks(torch, dist)
     lv = LEVELS[args.level]
     eng = tfhe_amd.Engine(dev.index)
     eng.use_torch_stream()
@@ -235,7 +254,7 @@ def side_workload(args):
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
@@ -302,7 +321,7 @@ def time_nand(eng, torch, dist, dev, world, rank, level, K, B, steps, warmup, ch
     prof = eng.profile_read()
     eng.profile_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     br_ms, br_cnt = prof["blind_rotate"]
@@ -387,16 +406,7 @@ def main():
 
     import tfhe_amd
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    world, rank, dev = init_ranks(torch, dist)
 
     eng = tfhe_amd.Engine(dev.index)
     eng.use_torch_stream()
@@ -409,9 +419,11 @@ def main():
         if rank == 0:
             K = (synthetic_keys if args.keys == "synthetic" else reference_style_keys)(level, 0xC0FFEE + 3)
             eng.load_keys(params, K["bk"], K["ks_a"], K["ks_b"], K["ks_var"])
+        progress(f"Bit{level} keys loaded on rank 0")
         if world > 1:
             from tfhe_amd import parallel
             parallel.replicate_keys(eng, params, dev, src=0)
+            progress(f"keys replicated to {world} ranks")
         return K
 
     B = args.batch
@@ -425,6 +437,7 @@ def main():
     else:
         main_res, tensors = time_nand(eng, torch, dist, dev, world, rank, args.level, K, B, args.steps,
                                       args.warmup)
+    progress(f"timed {args.steps} steps: {main_res['value']:.0f} gates/s")
     p50 = p50_host = None
     if rank == 0 and not args.no_latency:
         p50, p50_host = latency(eng, torch, tensors, lv["n"])

@@ -459,6 +459,27 @@ def test_multi_context_rccl_replication_in_a_fresh_process():
     assert "MSG keys replicated over RCCL" in r.stdout, r.stdout + r.stderr
 
 
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per
+    rank), rehearsed on one GPU: both ranks on GPU 0 over gloo.  Exercises rank 0's key load,
+    the export -> broadcast -> import of the device blobs on the other rank, sharding with
+    shard_bounds, the max-over-ranks timing and the check of a timed output against the oracle.
+    (Throughput of such a run means nothing.)"""
+    import json
+    env = dict(os.environ, TFHE_BENCH_REHEARSE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--total-gates", "3001", "--batch", "1024", "--steps", "1", "--warmup", "0",
+           "--no-latency", "--no-bit128", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["value"] > 0
+    assert res["output_check"]["matches_oracle"] is True
+    assert res["roofline"]["launches"] == 2        # rank 0's shard: 1501 gates in launches of 1024
+
+
 # ---- circuits::compare and circuits::eq, level-batched -----------------------------------------
 
 def _oracle_compare(P, K, a, b, mode):

@@ -21,10 +21,16 @@ def shard_bounds(total, rank, world):
 
 def broadcast_blobs(blobs, src=0, group=None):
     """Broadcasts a list of uint8 tensors in place from rank `src`."""
+    staged = dist.get_backend(group) == "gloo"      # gloo moves host memory: stage device blobs
     for b in blobs:
         if b.dtype != torch.uint8 or not b.is_contiguous():
             raise ValueError("blobs must be contiguous uint8 tensors")
-        dist.broadcast(b, src, group=group)
+        if staged and b.device.type != "cpu":
+            h = b.cpu()
+            dist.broadcast(h, src, group=group)
+            b.copy_(h)
+        else:
+            dist.broadcast(b, src, group=group)
     return blobs
 
 
