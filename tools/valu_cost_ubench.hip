@@ -7,7 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 template <int OP>
-__global__ __launch_bounds__(256, 1) void k(unsigned long long* out, double seed, int iters) {
+__global__ __launch_bounds__(1024) void k(unsigned long long* out, double seed, int iters) {
   double x[16]; float f[16]; unsigned a[16];
   for (int i = 0; i < 16; i++) { x[i] = seed + i + threadIdx.x; f[i] = (float)x[i]; a[i] = i; }
   double w = 1.0000001, z = 0.5; float wf = 1.0001f, zf = 0.5f;
@@ -37,20 +37,22 @@ __global__ __launch_bounds__(256, 1) void k(unsigned long long* out, double seed
   double s = 0; for (int i = 0; i < 16; i++) s += x[i] + f[i] + a[i];
   if (s == 12345.678) out[1] = 1;
 }
-template <int OP> void run(const char* name, unsigned long long* d, int blocks) {
+template <int OP> void run(const char* name, unsigned long long* d, int blocks, int threads = 256) {
   unsigned long long h[3];
   const int iters = 20000;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  k<OP><<<blocks, 256>>>(d, 1.0, iters);
+  k<OP><<<blocks, threads>>>(d, 1.0, iters);
   hipEventRecord(e0);
-  k<OP><<<blocks, 256>>>(d, 1.0, iters);
+  k<OP><<<blocks, threads>>>(d, 1.0, iters);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
   const double n = (double)iters * 64;
-  printf("%-34s blocks %3d: %5.2f clock64 ticks, %6.3f ns (events), %6.3f wall_clock64 ticks per instruction\n", name, blocks,
-         h[0] / n, ms * 1e6 / n, h[2] / n);
+  // FMA-equivalent rate of the whole launch: 64 lanes x 2 flop per wave-instruction
+  const double tflops = (double)blocks * (threads / 64) * n * 128.0 / (ms * 1e-3) / 1e12;
+  printf("%-28s blocks %3d x %4d threads: %5.2f clock64 ticks, %6.3f ns per instruction of a wavefront, "
+         "%5.1f T lane-FMA-flop/s\n", name, blocks, threads, h[0] / n, ms * 1e6 / n, tflops);
 }
 int main() {
   unsigned long long* d; hipMalloc(&d, 32);
@@ -65,6 +67,12 @@ int main() {
     run<3>("v_fma_f32", d, blocks);
     run<4>("v_mov_b32", d, blocks);
     run<5>("v_accvgpr_write_b32", d, blocks);
+  }
+  // more wavefronts per SIMD: the per-SIMD rate, not only the per-wavefront cadence
+  for (int threads : {512, 1024}) {
+    run<1>("v_fma_f64 v,v,v,v", d, 256, threads);
+    run<0>("v_add_f64 v,v,v", d, 256, threads);
+    run<3>("v_fma_f32", d, 256, threads);
   }
   return 0;
 }
