@@ -44,6 +44,10 @@ sys.path.insert(0, ROOT)
 FLOP_FFT = 2.5 * 2048 * 11
 FLOP_POINTWISE = 6 * 1025
 FP64_VECTOR_PEAK_TFLOPS = 78.6      # MI355X datasheet, vector FP64
+# what a stream of independent v_fma_f64 reaches on the GPU box at this kernel's occupancy (one
+# wavefront per SIMD; tools/valu_cost_ubench.hip, profiles/r02_valu_cost_ubench.txt): reported
+# beside the datasheet peak, never used for `frac`
+FP64_MEASURED_FMA_STREAM_TFLOPS = 58.7
 
 
 def flop_per_iteration(l):
@@ -337,6 +341,7 @@ def time_nand(eng, torch, dist, dev, world, rank, level, K, B, steps, warmup, ch
         "roofline": {"bound": "fp64_valu", "kernel": "blind_rotate_kernel",
                      "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
+                     "measured_fma_stream_peak": FP64_MEASURED_FMA_STREAM_TFLOPS,
                      "traffic": traffic, "traffic_profiled_from": traffic_from,
                      "flop_per_launch": flop_launch, "avg_launch_ms": br_avg_s * 1e3,
                      "launches": br_cnt},
