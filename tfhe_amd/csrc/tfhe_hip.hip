@@ -66,14 +66,6 @@ struct StampCtx {
 #define TFHE_K1_DEPTH 4
 #endif
 
-// The isolated-product kernel the entry points launch: polymul2_kernel (one parked
-// spectrum, operands prefetched by LDS DMA) or polymul_kernel (the first form).
-#ifndef TFHE_POLYMUL_CHUNK
-#define TFHE_POLYMUL_CHUNK 4
-#endif
-#ifndef TFHE_POLYMUL_KERNEL
-#define TFHE_POLYMUL_KERNEL polymul2_kernel
-#endif
 
 // Where the accumulator of the blind rotation lives between uses: parked in
 // accumulation registers by hand (0) or left to the register allocator (1).
@@ -263,7 +255,7 @@ __device__ __forceinline__ void level_product(int p, const char* tt, const cplx*
 struct NoMargin {
   __device__ __forceinline__ void track(double) {}
 };
-// Largest |x - rint(x)| seen before rounding (see polymul_kernel).
+// Largest |x - rint(x)| seen before rounding (see polymul2_kernel).
 struct Margin {
   double all = 0.0, deciding = 0.0;
   __device__ __forceinline__ void track(double x) {
@@ -702,141 +694,10 @@ __global__ __launch_bounds__(kBlock, 1) void bk_fft_kernel(const int32_t* __rest
   });
 }
 
-// poly_multiplier / torus_polynomial_mul_r on independent pairs.  One
-// wavefront multiplies two pairs: FFT(d_a + i d_b), FFT(s_a + i s_b), the four
-// real spectra are separated with the mirror, Z = D_a S_a + i D_b S_b, and one
-// inverse transform returns product a in the real part, product b in the
-// imaginary part.
-//
-// MARGIN (test hook): nothing is written to out; margin [B][2] receives, per
-// product, the largest |x - rint(x)| over all 2N-1 coefficients before rounding
-// and the largest over the coefficients whose rounding decides the result
-// (|rint(x)| <= 2^31; beyond that the cast saturates whatever the fraction is).
-template <bool ACCUMULATE, bool MARGIN>
-__global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __restrict__ d,
-                                                            const int32_t* __restrict__ s,
-                                                            const cplx* __restrict__ tables,
-                                                            int32_t* __restrict__ out,
-                                                            double* __restrict__ margin, int B) {
-  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
-  char* lds_tables = lds + kWavesPerBlock * wfft::kWaveBytes;
-  load_tables(lds_tables, tables);
-  const cplx* tE = reinterpret_cast<const cplx*>(lds_tables);
-  const cplx* tw = tE + 1024;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = lane >> 5, q = lane & 31;
-  char* wave_tiles = lds + wave * wfft::kWaveBytes;
-  // persistent workgroups: the tables are loaded once per compute unit
-#pragma unroll 1
-  for (int pair = blockIdx.x * kWavesPerBlock + wave; 2 * pair < B; pair += gridDim.x * kWavesPerBlock) {
-  const int ia = 2 * pair, ib = 2 * pair + 1;
-  const bool has_b = ib < B;
-
-  double re[32], im[32];
-  unsigned park[256];      // 2 D_a and 2 D_b, parked in accumulation registers
-  static_for<0, 32>([&](auto ic) WFFT_INLINE {
-    constexpr int r = decltype(ic)::value;
-    re[r] = (double)d[(size_t)ia * kN + q + 32 * r];
-    im[r] = has_b ? (double)d[(size_t)ib * kN + q + 32 * r] : 0.0;
-  });
-  wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
-  // With C = FFT(d_a + i d_b) and (cx, cy) = C[-k]: Ct = (cx, -cy),
-  // 2 D_a = C + Ct = (re + cx, im - cy), 2 D_b = -i (C - Ct) = (im + cy, cx - re).
-  // The mirror tile carries the real parts first, then the imaginary parts.
-  const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
-  wfft::mirror_store(re, ml);
-  static_for<0, 32>([&](auto ic) WFFT_INLINE {
-    constexpr int p = decltype(ic)::value;
-    const double cx = wfft::mirror_load<p>(ml);
-    wfft::agpr_put_f64(re[p] + cx, park[8 * p + 0], park[8 * p + 1]);
-    wfft::agpr_put_f64(cx - re[p], park[8 * p + 6], park[8 * p + 7]);
-  });
-  wfft::mirror_store(im, ml);
-  static_for<0, 32>([&](auto ic) WFFT_INLINE {
-    constexpr int p = decltype(ic)::value;
-    const double cy = wfft::mirror_load<p>(ml);
-    wfft::agpr_put_f64(im[p] - cy, park[8 * p + 2], park[8 * p + 3]);
-    wfft::agpr_put_f64(im[p] + cy, park[8 * p + 4], park[8 * p + 5]);
-  });
-  wfft::wave_lds_fence();
-  static_for<0, 32>([&](auto ic) WFFT_INLINE {
-    constexpr int r = decltype(ic)::value;
-    re[r] = (double)s[(size_t)ia * kN + q + 32 * r];
-    im[r] = has_b ? (double)s[(size_t)ib * kN + q + 32 * r] : 0.0;
-  });
-  wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
-  constexpr double kScale = 1.0 / (4.0 * 2048.0);
-  double sx[32];
-  wfft::mirror_store(re, ml);
-  static_for<0, 32>([&](auto ic) WFFT_INLINE { sx[decltype(ic)::value] = wfft::mirror_load<decltype(ic)::value>(ml); });
-  wfft::mirror_store(im, ml);
-  static_for<0, 32>([&](auto ic) WFFT_INLINE {
-    constexpr int p = decltype(ic)::value;
-    const double cy = wfft::mirror_load<p>(ml);
-    const double dar = wfft::agpr_get_f64(park[8 * p + 0], park[8 * p + 1]);
-    const double dai = wfft::agpr_get_f64(park[8 * p + 2], park[8 * p + 3]);
-    const double dbr = wfft::agpr_get_f64(park[8 * p + 4], park[8 * p + 5]);
-    const double dbi = wfft::agpr_get_f64(park[8 * p + 6], park[8 * p + 7]);
-    const double sar = re[p] + sx[p], sai = im[p] - cy;
-    const double sbr = im[p] + cy, sbi = sx[p] - re[p];
-    const double zar = dar * sar - dai * sai, zai = dar * sai + dai * sar;
-    const double zbr = dbr * sbr - dbi * sbi, zbi = dbr * sbi + dbi * sbr;
-    re[p] = (zar - zbi) * kScale;      // Z = Z_a + i Z_b
-    im[p] = (zai + zbr) * kScale;
-  });
-  wfft::wave_lds_fence();
-  // Inverse transform; the second half of the outputs (t >= N) is E - twist*O.
-  wfft::fft1024_inv(re, im, wave_tiles + h * wfft::kHalfBytes, tE, q);
-  wfft::twist_odd_half<true>(re, im, tE, tw, q, h);
-  const int prod = h ? ib : ia;        // half E ends with product a, half O with product b
-  const bool live = h ? has_b : true;
-  double m_all = 0.0, m_dec = 0.0;
-  auto track = [&](double x) WFFT_INLINE {
-    const double rx = rint(x), f = fabs(x - rx);
-    m_all = fmax(m_all, f);
-    if (fabs(rx) <= 2147483648.0) m_dec = fmax(m_dec, f);
-  };
-  static_for<0, 32>([&](auto ic) WFFT_INLINE {
-    constexpr int r = decltype(ic)::value;
-    const int t = q + 32 * r;
-    // e = (E: Re E | O: Im E), o = (E: Re twO | O: Im twO)
-    double e = re[r], o = im[r];
-    wfft::swap_halves(e, o);
-    const double lo = e + o;
-    const double hi_ = e - o;
-    if (MARGIN) {
-      track(lo);
-      if (t < kN - 1) track(hi_);
-    } else if (live) {
-      if (ACCUMULATE) {
-        int32_t* dst = out + (size_t)prod * kN + t;
-        *dst = wadd(*dst, wfft::round_sat_i32(lo));
-      } else {
-        int32_t* dst = out + (size_t)prod * (2 * kN - 1);
-        dst[t] = wfft::round_sat_i32(lo);
-        if (t < kN - 1) dst[kN + t] = wfft::round_sat_i32(hi_);
-      }
-    }
-  });
-  if (MARGIN) {
-    // largest value of each half-wave (one product per half)
-    for (int off = 16; off >= 1; off >>= 1) {
-      m_all = fmax(m_all, __shfl_xor(m_all, off, 64));
-      m_dec = fmax(m_dec, __shfl_xor(m_dec, off, 64));
-    }
-    if (live && q == 0) {
-      margin[2 * (size_t)prod + 0] = m_all;
-      margin[2 * (size_t)prod + 1] = m_dec;
-    }
-  }
-  }
-}
-
-// poly_multiplier / torus_polynomial_mul_r on independent pairs, second form (the one
-// the entry points launch).  Same packing as polymul_kernel (two products per wavefront,
-// one inverse transform), arranged so that only ONE spectrum is parked and no operand
-// load is waited for:
+// poly_multiplier / torus_polynomial_mul_r on independent pairs.  One wavefront multiplies
+// two pairs: FFT(d_a + i d_b), FFT(s_a + i s_b), and one inverse transform returns product a
+// in the real part, product b in the imaginary part.  Arranged so that only ONE spectrum is
+// parked and no operand load is waited for:
 //   * with P = FFT(d_a + i d_b), Q = FFT(s_a + i s_b) and X'[k] = conj(X[-k]), the
 //     spectrum of product a + i product b is
 //       Z = ((P + P')(Q + Q') - i (P - P')(Q - Q')) / 4 = (W1 + W2') / 4,
@@ -847,6 +708,11 @@ __global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __res
 //   * the operands of the NEXT pair are copied global -> LDS by the DMA path
 //     (global_load_lds, no registers) while this pair's inverse transform runs; the same
 //     16 KiB of the wavefront's LDS share serve as the second mirror tile in between.
+//
+// MARGIN (test hook): nothing is written to out; margin [B][2] receives, per
+// product, the largest |x - rint(x)| over all 2N-1 coefficients before rounding
+// and the largest over the coefficients whose rounding decides the result
+// (|rint(x)| <= 2^31; beyond that the cast saturates whatever the fraction is).
 typedef __attribute__((address_space(3))) void* lds_dma_ptr;
 
 template <int P>
@@ -2276,9 +2142,9 @@ int tfhe_hip_polymul_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, 
   const unsigned grid = (unsigned)std::min<size_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock,
                                                    (size_t)ctx->num_cus);
   if (accumulate)
-    hipLaunchKernelGGL((TFHE_POLYMUL_KERNEL<true, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (double*)nullptr, (int)B);
+    hipLaunchKernelGGL((polymul2_kernel<true, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (double*)nullptr, (int)B);
   else
-    hipLaunchKernelGGL((TFHE_POLYMUL_KERNEL<false, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (double*)nullptr, (int)B);
+    hipLaunchKernelGGL((polymul2_kernel<false, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (double*)nullptr, (int)B);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
@@ -2467,7 +2333,7 @@ int tfhe_hip_polymul_margin_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32
   const size_t pairs = (B + 1) / 2;
   const unsigned grid = (unsigned)std::min<size_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock,
                                                    (size_t)ctx->num_cus);
-  hipLaunchKernelGGL((TFHE_POLYMUL_KERNEL<false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s,
+  hipLaunchKernelGGL((polymul2_kernel<false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s,
                      ctx->tables, (int32_t*)nullptr, margin, (int)B);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
