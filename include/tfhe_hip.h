@@ -314,7 +314,13 @@ int tfhe_hip_circuit_eq_dev(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_t
 /* poly_multiplier / torus_polynomial_mul_r (src/numerics.rs:138-155,185-261)
  * on B independent pairs of N-coefficient polynomials d [B][N], s [B][N].
  * accumulate == 0: out [B][2N-1] = the full saturated product;
- * accumulate != 0: out [B][N] += first N coefficients (wrapping). */
+ * accumulate != 0: out [B][N] += first N coefficients (wrapping).
+ * The result equals the exact integer convolution (rounded, saturated) as long as
+ * an f64 FFT can resolve it: for every operand the path produces (|d| <= Bg/2 <=
+ * 2^10 against any Torus32 polynomial) the distance to the nearest rounding
+ * boundary stays above 0.19 (tfhe_hip_polymul_margin).  With |d| near 2^15 and
+ * beyond, exact coefficients approach 2^53 and no f64 FFT, the reference's
+ * included, determines the integer result any more. */
 int tfhe_hip_polymul(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, int32_t* out,
                      int accumulate, size_t B);
 int tfhe_hip_polymul_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, int32_t* out,
