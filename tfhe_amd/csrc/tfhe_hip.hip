@@ -108,7 +108,8 @@ __device__ __forceinline__ MonomialPower monomial_power(int power) {
   return {power % kN, ((power / kN) & 1) != 0};
 }
 
-// Copies the two twiddle tables (tE then twist, 1024 entries each) into LDS.
+// Copies the two twiddle tables (tE = w1024^(q kb), then tq = w4096^n, 1024 entries each)
+// into LDS.
 __device__ __forceinline__ void load_tables(char* lds_tables, const cplx* __restrict__ tables) {
   cplx* dst = reinterpret_cast<cplx*>(lds_tables);
   for (int i = threadIdx.x; i < 2048; i += blockDim.x) dst[i] = tables[i];
@@ -145,97 +146,60 @@ constexpr uint32_t tt_mask() {
 //            to i32 on its own before the wrapping add, as the reference does.
 // bk       : FFT-domain key of this iteration, [l][2][32][64] cplx.
 // ---------------------------------------------------------------------------
-// One decomposition level of the external product: digits of level p of both
-// polynomials, one forward transform, the two real spectra D_0 and D_1, their
-// products with the two key columns of the level, two inverse transforms; each
-// rounded coefficient is handed to accumulate(integral_constant<r>, value) by
-// lane (h, q) for coefficient t = q + 32 r of result polynomial u = h.
+// One decomposition level of the external product.  Half-wave h takes digit
+// polynomial h (the level-p digits of accumulator polynomial h): its twisted
+// transform D_h (wave_fft.hpp), then the two products with the key polynomials
+// of TGSW row (h, p): D_h * K_{h,h} contributes to result polynomial h, which is
+// the one this half accumulates, and D_h * K_{h,1-h} to the other half's.  Each
+// rounded coefficient is handed to accumulate(integral_constant<r>, value,
+// bool_constant<CROSS>) by lane (h, q) for coefficient t = q + 32 r; CROSS says
+// that it belongs to result polynomial 1 - h.
 // tt: this lane's base (+ 8 q) into the [N][2] int32 sample (XORed with tt_mask).
-// bk_level: [2][32][64] cplx, the two key columns of the level.
+// bk_level: [2][32][64] cplx: block 0 holds K_{h,h}, block 1 K_{h,1-h} in lane (h, q).
 template <int BGBIT, class Acc>
 __device__ __forceinline__ void level_product(int p, const char* tt, const cplx* __restrict__ bk_level,
-                                              char* wave_tiles, const cplx* tE, const cplx* tw,
+                                              char* wave_tiles, const cplx* tE, const cplx* tq,
                                               int lane, Acc&& accumulate, StampCtx& st) {
   const int h = lane >> 5, q = lane & 31;
+  char* tile = wave_tiles + h * wfft::kHalfBytes;
   double re[32], im[32];
-  unsigned hold[128];      // parked spectrum D_1
-  // gadget decomposition, src/tgsw.rs:299-328 (offset 0x80000000, tgsw.rs:50-52);
-  // every lane needs the digits of both polynomials: c = d_{p,0} + i d_{p,1}.
+  unsigned hold[128];      // parked spectrum D_h
+  // gadget decomposition, src/tgsw.rs:299-328 (offset 0x80000000, tgsw.rs:50-52)
   const int decal = 32 - (p + 1) * BGBIT;
+  const char* th = tt + 4 * h;
   wfft::wave_lds_fence();
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
-    const int2 t = *reinterpret_cast<const int2*>(tt + r * 256);
-    re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t.x, decal, BGBIT);
-    im[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t.y, decal, BGBIT);
+    const int32_t t = *reinterpret_cast<const int32_t*>(th + r * 256);
+    re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t, decal, BGBIT);
   });
-  // C = FFT(c); the two real spectra are separated with the mirror:
-  // D_0 = C + Ct, D_1 = -i (C - Ct) with Ct[k] = conj(C[-k]); the factor 1/2
-  // is folded into the key.
   TFHE_STAMP(st, 1);
-  wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+  wfft::fwd1024_twisted_real(re, im, tile, tE, tq, q);
   TFHE_STAMP(st, 2);
   const cplx* b0 = bk_level + lane;
   const cplx* b1 = bk_level + 2048 + lane;
   auto load_k0 = [&](auto ic) WFFT_INLINE { return b0[decltype(ic)::value * 64]; };
   auto load_k1 = [&](auto ic) WFFT_INLINE { return b1[decltype(ic)::value * 64]; };
   {
-    // Z_0 = D_0 * key_0 in place; D_1 is parked.  The first loads of key
-    // column 0 are issued before the mirror passes.  Real parts go through
-    // the tile first, then the imaginary parts.
+    // Z = D_h * K_{h,h} in place; a copy of D_h is parked for the second product
     wfft::Pipe32<4, TFHE_K0_DEPTH, cplx> k0p;
     k0p.prologue(load_k0);
-    const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
-    wfft::mirror_store(re, ml);
-    TFHE_STAMP(st, 3);
-    wfft::pipelined_for32<TFHE_MIRROR_GROUP, double>(
-        [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
-        [&](auto ic, const double& ctx) WFFT_INLINE {
-          constexpr int s = decltype(ic)::value;
-          const double c = re[s];
-          re[s] = c + ctx;                                            // Re D_0
-          wfft::agpr_put_f64(ctx - c, hold[4 * s + 2], hold[4 * s + 3]);   // Im D_1
-        });
-    wfft::mirror_store(im, ml);
-    auto load_my = [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); };
-    wfft::Pipe32<4, 1, double> myp;
-    myp.prologue(load_my);
-    static_for<0, 8>([&](auto gc) WFFT_INLINE {
-      constexpr int g = decltype(gc)::value;
-      if constexpr (g + TFHE_K0_DEPTH < 8) {
-        static_for<0, 4>([&](auto ic) WFFT_INLINE {
-          constexpr int e = decltype(ic)::value;
-          k0p.buf[(g + TFHE_K0_DEPTH) % (TFHE_K0_DEPTH + 1)][e] =
-              load_k0(std::integral_constant<int, (g + TFHE_K0_DEPTH) * 4 + e>{});
-        });
-      }
-      if constexpr (g + 1 < 8) {
-        static_for<0, 4>([&](auto ic) WFFT_INLINE {
-          constexpr int e = decltype(ic)::value;
-          myp.buf[(g + 1) % 2][e] = load_my(std::integral_constant<int, (g + 1) * 4 + e>{});
-        });
-      }
-      static_for<0, 4>([&](auto ic) WFFT_INLINE {
-        constexpr int e = decltype(ic)::value;
-        constexpr int s = g * 4 + e;
-        const double my = myp.buf[g % 2][e];          // Im C[-k]; Ct = (.., -my)
-        wfft::agpr_put_f64(im[s] + my, hold[4 * s + 0], hold[4 * s + 1]);   // Re D_1
-        im[s] = im[s] - my;                                                 // Im D_0
-      });
-      static_for<0, 2>([&](auto ic) WFFT_INLINE {
-        constexpr int e = 2 * decltype(ic)::value;
-        constexpr int s = g * 4 + e;
-        wfft::cmul2<false>(re[s], im[s], k0p.buf[g % (TFHE_K0_DEPTH + 1)][e], re[s + 1], im[s + 1],
-                           k0p.buf[g % (TFHE_K0_DEPTH + 1)][e + 1]);
-      });
-      __builtin_amdgcn_sched_barrier(0);
+    k0p.run2(load_k0, [&](auto i0, const cplx& ka, auto i1, const cplx& kb) WFFT_INLINE {
+      constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;
+      wfft::agpr_put_f64(re[s0], hold[4 * s0 + 0], hold[4 * s0 + 1]);
+      wfft::agpr_put_f64(im[s0], hold[4 * s0 + 2], hold[4 * s0 + 3]);
+      wfft::agpr_put_f64(re[s1], hold[4 * s1 + 0], hold[4 * s1 + 1]);
+      wfft::agpr_put_f64(im[s1], hold[4 * s1 + 2], hold[4 * s1 + 3]);
+      wfft::cmul2<false>(re[s0], im[s0], ka, re[s1], im[s1], kb);
     });
   }
   TFHE_STAMP(st, 4);
-  wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate, []() WFFT_INLINE {});
+  wfft::inv1024_twisted_real<false>(
+      re, im, tile, tE, tq, q,
+      [&](auto rc, double v) WFFT_INLINE { accumulate(rc, v, std::false_type{}); }, [](auto, double) {});
   TFHE_STAMP(st, 5);
   {
-    // Z_1 = D_1 * key_1 as D_1 comes back from the accumulation registers.
+    // Z = D_h * K_{h,1-h} as D_h comes back from the accumulation registers
     wfft::Pipe32<4, TFHE_K1_DEPTH, cplx> k1p;
     k1p.prologue(load_k1);
     k1p.run2(load_k1, [&](auto i0, const cplx& ka, auto i1, const cplx& kb) WFFT_INLINE {
@@ -248,14 +212,16 @@ __device__ __forceinline__ void level_product(int p, const char* tt, const cplx*
     });
   }
   TFHE_STAMP(st, 6);
-  wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate, []() WFFT_INLINE {});
+  wfft::inv1024_twisted_real<false>(
+      re, im, tile, tE, tq, q,
+      [&](auto rc, double v) WFFT_INLINE { accumulate(rc, v, std::true_type{}); }, [](auto, double) {});
   TFHE_STAMP(st, 7);
 }
 
 struct NoMargin {
   __device__ __forceinline__ void track(double) {}
 };
-// Largest |x - rint(x)| seen before rounding (see polymul2_kernel).
+// Largest |x - rint(x)| seen before rounding (see polymul_kernel).
 struct Margin {
   double all = 0.0, deciding = 0.0;
   __device__ __forceinline__ void track(double x) {
@@ -267,17 +233,21 @@ struct Margin {
 
 template <int L, int BGBIT, class M = NoMargin>
 __device__ __forceinline__ void extprod_accumulate(unsigned (&acc_a)[32], const cplx* __restrict__ bk,
-                                                   char* wave_lds, const cplx* tE, const cplx* tw,
+                                                   char* wave_lds, const cplx* tE, const cplx* tq,
                                                    int lane, StampCtx& st, M&& margin = M{}) {
   const char* tt = wave_lds + kTtOff + (lane & 31) * 8;
-  auto accumulate = [&](auto rc, double v) WFFT_INLINE {
+  // the other half-wave's lane, as a ds_bpermute address
+  const int partner = (lane ^ 32) << 2;
+  auto accumulate = [&](auto rc, double v, auto cross) WFFT_INLINE {
     constexpr int r = decltype(rc)::value;
     margin.track(v);
-    acc_a[r] = acc_put((unsigned)wadd((int32_t)acc_get(acc_a[r]), wfft::round_sat_i32(v)));
+    int32_t x = wfft::round_sat_i32(v);
+    if constexpr (decltype(cross)::value) x = __builtin_amdgcn_ds_bpermute(partner, x);
+    acc_a[r] = acc_put((unsigned)wadd((int32_t)acc_get(acc_a[r]), x));
   };
 #pragma unroll 1
   for (int p = 0; p < L; p++)
-    level_product<BGBIT>(p, tt, bk + (size_t)p * 2 * 2048, wave_lds, tE, tw, lane, accumulate, st);
+    level_product<BGBIT>(p, tt, bk + (size_t)p * 2 * 2048, wave_lds, tE, tq, lane, accumulate, st);
 }
 
 // t = X^abar (prev + acc) - acc for polynomials 0 and 1
@@ -373,7 +343,7 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
   char* lds_tables = lds + kWavesPerBlock * wfft::kWaveBytes;
   load_tables(lds_tables, args.tables);
   const cplx* tE = reinterpret_cast<const cplx*>(lds_tables);
-  const cplx* tw = tE + 1024;
+  const cplx* tq = tE + 1024;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform, kept scalar
@@ -412,7 +382,7 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
     TFHE_STAMP(st, 8);
     rotate_diff<HOOK>(acc_a, abar, wave_tiles, ln, tt_mask<L, BGBIT>());   // also prev <- acc
     TFHE_STAMP(st, 0);
-    extprod_accumulate<L, BGBIT>(acc_a, args.bkfft + (size_t)i * L * 2 * 2048, wave_tiles, tE, tw, ln,
+    extprod_accumulate<L, BGBIT>(acc_a, args.bkfft + (size_t)i * L * 2 * 2048, wave_tiles, tE, tq, ln,
                                  st);
 #ifdef TFHE_STAMPS
     if (i == args.n - 1 && b == args.B / 2 && lane == 0)
@@ -463,12 +433,11 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
 // the registers.
 //
 // LDS: per wavefront the FFT exchange area, then per workgroup prev [2][N],
-// acc [2][N], tt [N][2] and tt with its two polynomials swapped [N][2] (int32),
-// then the twiddle tables.
+// acc [2][N], tt [N][2] (int32), then the twiddle tables.
 // ---------------------------------------------------------------------------
 template <int W>
 constexpr int split_lds_bytes() {
-  return W * wfft::kExchangeBytes + 4 * 2 * kN * 4 + kTableBytes;
+  return W * wfft::kExchangeBytes + 3 * 2 * kN * 4 + kTableBytes;
 }
 
 template <int L, int BGBIT, bool HOOK, int CPW>
@@ -480,25 +449,27 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
   int32_t* prevL = reinterpret_cast<int32_t*>(shared);
   int32_t* accL = prevL + 2 * kN;
   int32_t* ttL = accL + 2 * kN;
-  int32_t* ttS = ttL + 2 * kN;          // (polynomial 1, polynomial 0) per coefficient
-  char* lds_tables = shared + 4 * 2 * kN * 4;
+  char* lds_tables = shared + 3 * 2 * kN * 4;
   load_tables(lds_tables, args.tables);
   const cplx* tE = reinterpret_cast<const cplx*>(lds_tables);
-  const cplx* tw = tE + 1024;
+  const cplx* tq = tE + 1024;
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int h = lane >> 5, q = lane & 31;
-  const int p = CPW == 1 ? wave >> 1 : wave, j = wave & 1;
+  // CPW == 1: this wavefront's level p and result polynomial u
+  const int p = CPW == 1 ? wave >> 1 : wave, u = wave & 1;
   char* wave_tiles = lds + wave * wfft::kExchangeBytes;
   const int b = blockIdx.x;
   constexpr uint32_t kMaskTt = tt_mask<L, BGBIT>();
   const int decal = 32 - (p + 1) * BGBIT;
   StampCtx st;
   // wrapping add of a rounded, saturated product (numerics.rs:138-155)
-  auto accumulate = [&](auto rc, double v) WFFT_INLINE {
+  // (CROSS: the product belongs to the result polynomial of the other half-wave)
+  auto accumulate = [&](auto rc, double v, auto cross) WFFT_INLINE {
     constexpr int r = decltype(rc)::value;
-    atomicAdd(reinterpret_cast<unsigned*>(accL) + h * kN + q + 32 * r, (unsigned)wfft::round_sat_i32(v));
+    const int poly = decltype(cross)::value ? 1 - h : h;
+    atomicAdd(reinterpret_cast<unsigned*>(accL) + poly * kN + q + 32 * r, (unsigned)wfft::round_sat_i32(v));
   };
 
   for (int x = threadIdx.x; x < 2 * kN; x += 64 * W) {
@@ -532,9 +503,7 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
           const int32_t v = wadd(prevL[h * kN + src], accL[h * kN + src]);
           const int32_t a = accL[h * kN + n];
           const int32_t x = ((base < -32 * r) != mp.cycle) ? wneg(v) : v;
-          const int32_t tv = (int32_t)((uint32_t)wsub(x, a) ^ kMaskTt);
-          ttL[2 * n + h] = tv;
-          if constexpr (CPW == 1) ttS[2 * n + 1 - h] = tv;
+          ttL[2 * n + h] = (int32_t)((uint32_t)wsub(x, a) ^ kMaskTt);
           keep[e] = a;
         }
       });
@@ -549,47 +518,39 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
     }
     const char* tt = reinterpret_cast<const char*>(ttL) + q * 8;
     if constexpr (CPW == 2) {
-      level_product<BGBIT>(p, tt, args.bkfft + ((size_t)i * L + p) * 2 * 2048, wave_tiles, tE, tw, lane,
+      level_product<BGBIT>(p, tt, args.bkfft + ((size_t)i * L + p) * 2 * 2048, wave_tiles, tE, tq, lane,
                            accumulate, st);
     } else {
-    // this wavefront's (level, column) product.  Column 1 reads the sample with its two
-    // polynomials swapped, c' = d_{p,1} + i d_{p,0}: the spectrum it needs, that of
-    // d_{p,1}, is then C' + Ct' (Ct[k] = conj(C[-k])), the expression column 0 uses
-    // for d_{p,0}, so all four wavefronts run the same code.
-    const char* ttj = reinterpret_cast<const char*>(j ? ttS : ttL) + q * 8;
+    // this wavefront's level p and result polynomial u: half-wave h takes digit polynomial
+    // h, so both halves contribute (each rounded on its own) to the same result polynomial
+    char* tile = wave_tiles + h * wfft::kHalfBytes;
     double re[32], im[32];
     static_for<0, 32>([&](auto ic) WFFT_INLINE {
       constexpr int r = decltype(ic)::value;
-      const int2 t = *reinterpret_cast<const int2*>(ttj + r * 256);
-      re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t.x, decal, BGBIT);
-      im[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t.y, decal, BGBIT);
+      const int32_t t = *reinterpret_cast<const int32_t*>(tt + 4 * h + r * 256);
+      re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t, decal, BGBIT);
     });
     TFHE_STAMP(st, 3);
-    wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+    wfft::fwd1024_twisted_real(re, im, tile, tE, tq, q);
     TFHE_STAMP(st, 4);
-    const cplx* kcol = args.bkfft + ((size_t)i * L * 2 + (size_t)(p * 2 + j)) * 2048 + lane;
+    // K_{h,u}: block 0 of the level holds K_{h,h}, block 1 K_{h,1-h}
+    const cplx* kcol = args.bkfft + ((size_t)i * L + p) * 2 * 2048 + (h == u ? 0 : 2048) + lane;
     auto load_k = [&](auto ic) WFFT_INLINE { return kcol[decltype(ic)::value * 64]; };
     wfft::Pipe32<4, 3, cplx> kp;
     kp.prologue(load_k);
-    // D = C + Ct: Re = re + cx, Im = im - my with (cx, my) = C[-k]
-    const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
-    wfft::mirror_store(re, ml);
-    wfft::pipelined_for32<4, double>(
-        [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
-        [&](auto ic, const double& cx) WFFT_INLINE { re[decltype(ic)::value] += cx; });
-    wfft::mirror_store(im, ml);
-    wfft::pipelined_for32<4, double>(
-        [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
-        [&](auto ic, const double& my) WFFT_INLINE { im[decltype(ic)::value] -= my; });
     TFHE_STAMP(st, 5);
-    kp.run(load_k, [&](auto ic, const cplx& k) WFFT_INLINE {
-      constexpr int s = decltype(ic)::value;
-      const double dr = re[s], di = im[s];
-      re[s] = dr * k.x - di * k.y;
-      im[s] = dr * k.y + di * k.x;
+    kp.run2(load_k, [&](auto i0, const cplx& ka, auto i1, const cplx& kb) WFFT_INLINE {
+      constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;
+      wfft::cmul2<false>(re[s0], im[s0], ka, re[s1], im[s1], kb);
     });
     TFHE_STAMP(st, 6);
-    wfft::inv2048_first_half(re, im, wave_tiles, tE, tw, q, h, accumulate, []() WFFT_INLINE {});
+    wfft::inv1024_twisted_real<false>(
+        re, im, tile, tE, tq, q,
+        [&](auto rc, double v) WFFT_INLINE {
+          constexpr int r = decltype(rc)::value;
+          atomicAdd(reinterpret_cast<unsigned*>(accL) + u * kN + q + 32 * r, (unsigned)wfft::round_sat_i32(v));
+        },
+        [](auto, double) {});
     TFHE_STAMP(st, 7);
     }
   }
@@ -624,7 +585,7 @@ __global__ __launch_bounds__(kBlock, 1) void extprod_kernel(const int32_t* __res
   char* lds_tables = lds + kWavesPerBlock * wfft::kWaveBytes;
   load_tables(lds_tables, tables);
   const cplx* tE = reinterpret_cast<const cplx*>(lds_tables);
-  const cplx* tw = tE + 1024;
+  const cplx* tq = tE + 1024;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, q = lane & 31;
   const int b = blockIdx.x * kWavesPerBlock + wave;
@@ -640,7 +601,7 @@ __global__ __launch_bounds__(kBlock, 1) void extprod_kernel(const int32_t* __res
   StampCtx st;
   if constexpr (MARGIN) {
     Margin m;
-    extprod_accumulate<L, BGBIT>(acc_a, bk_i, wave_tiles, tE, tw, lane, st, m);
+    extprod_accumulate<L, BGBIT>(acc_a, bk_i, wave_tiles, tE, tq, lane, st, m);
     for (int off = 32; off >= 1; off >>= 1) {
       m.all = fmax(m.all, __shfl_xor(m.all, off, 64));
       m.deciding = fmax(m.deciding, __shfl_xor(m.deciding, off, 64));
@@ -650,7 +611,7 @@ __global__ __launch_bounds__(kBlock, 1) void extprod_kernel(const int32_t* __res
       margin[2 * (size_t)b + 1] = m.deciding;
     }
   } else {
-    extprod_accumulate<L, BGBIT>(acc_a, bk_i, wave_tiles, tE, tw, lane, st);
+    extprod_accumulate<L, BGBIT>(acc_a, bk_i, wave_tiles, tE, tq, lane, st);
   }
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
@@ -660,9 +621,11 @@ __global__ __launch_bounds__(kBlock, 1) void extprod_kernel(const int32_t* __res
 }
 
 // One-time transform of the bootstrapping key (replaces the per-call forward
-// FFT of the key polynomial at src/numerics.rs:216-238).  One wavefront per
-// (i, row, col): spectrum of a[0] + i a[1], scaled by 1/4096 (1/2048 for the
-// inverse transform, 1/2 for the real-spectrum separation).
+// FFT of the key polynomial at src/numerics.rs:216-238).  With K_{j,u} the key
+// polynomial that digit polynomial j multiplies for result polynomial u (flat
+// input [i][p][j][u][N]), wavefront (i, p, block) writes the twisted transforms
+// of K_{h,h} (block 0) or K_{h,1-h} (block 1) from half-wave h, scaled by 1/1024
+// for the unnormalised inverse transform.
 __global__ __launch_bounds__(kBlock, 1) void bk_fft_kernel(const int32_t* __restrict__ bk,
                                                            const cplx* __restrict__ tables,
                                                            cplx* __restrict__ bkfft, int count) {
@@ -670,44 +633,38 @@ __global__ __launch_bounds__(kBlock, 1) void bk_fft_kernel(const int32_t* __rest
   char* lds_tables = lds + kWavesPerBlock * wfft::kWaveBytes;
   load_tables(lds_tables, tables);
   const cplx* tE = reinterpret_cast<const cplx*>(lds_tables);
-  const cplx* tw = tE + 1024;
+  const cplx* tq = tE + 1024;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = lane >> 5, q = lane & 31;
-  const int s = blockIdx.x * kWavesPerBlock + wave;
+  const int s = blockIdx.x * kWavesPerBlock + wave;        // (i * l + p) * 2 + block
   if (s >= count) return;
   char* wave_tiles = lds + wave * wfft::kWaveBytes;
-  const int32_t* p0 = bk + (size_t)s * 2 * kN;
+  const int block = s & 1, u = block ? 1 - h : h;
+  const int32_t* p0 = bk + (((size_t)(s >> 1) * 2 + h) * 2 + u) * kN;
   double re[32], im[32];
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int r = decltype(ic)::value;
     re[r] = (double)p0[q + 32 * r];
-    im[r] = (double)p0[kN + q + 32 * r];
   });
-  wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+  wfft::fwd1024_twisted_real(re, im, wave_tiles + h * wfft::kHalfBytes, tE, tq, q);
   cplx* dst = bkfft + (size_t)s * 2048 + lane;
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int p = decltype(ic)::value;
     cplx v;
-    v.x = re[p] * (1.0 / 4096.0);
-    v.y = im[p] * (1.0 / 4096.0);
+    v.x = re[p] * (1.0 / 1024.0);
+    v.y = im[p] * (1.0 / 1024.0);
     dst[p * 64] = v;
   });
 }
 
-// poly_multiplier / torus_polynomial_mul_r on independent pairs.  One wavefront multiplies
-// two pairs: FFT(d_a + i d_b), FFT(s_a + i s_b), and one inverse transform returns product a
-// in the real part, product b in the imaginary part.  Arranged so that only ONE spectrum is
-// parked and no operand load is waited for:
-//   * with P = FFT(d_a + i d_b), Q = FFT(s_a + i s_b) and X'[k] = conj(X[-k]), the
-//     spectrum of product a + i product b is
-//       Z = ((P + P')(Q + Q') - i (P - P')(Q - Q')) / 4 = (W1 + W2') / 4,
-//       W1 = S - i T, W2 = S + i T, S = P Q + P Q', T = P Q - P Q'
-//     (P' Q' and P' Q are the mirror images of P Q and P Q'), so P is needed once per bin,
-//     straight from the accumulation registers, and the two mirror exchanges are those of Q
-//     and of W2;
-//   * the operands of the NEXT pair are copied global -> LDS by the DMA path
-//     (global_load_lds, no registers) while this pair's inverse transform runs; the same
-//     16 KiB of the wavefront's LDS share serve as the second mirror tile in between.
+// poly_multiplier / torus_polynomial_mul_r on independent pairs.  One half-wave per product:
+// the twisted transforms of d and s (wave_fft.hpp), their pointwise product, and one inverse
+// transform whose untwisted real part is the low half of the linear convolution and whose
+// negated imaginary part is the high half.  The two half-waves of a wavefront work on two
+// products in the same instructions and never exchange data.
+//   * the spectrum of d waits in the accumulation registers while s is transformed;
+//   * the operands of the NEXT pair of products are copied global -> LDS by the DMA path
+//     (global_load_lds, no registers) as soon as this pair's operands have been read.
 //
 // MARGIN (test hook): nothing is written to out; margin [B][2] receives, per
 // product, the largest |x - rint(x)| over all 2N-1 coefficients before rounding
@@ -715,27 +672,21 @@ __global__ __launch_bounds__(kBlock, 1) void bk_fft_kernel(const int32_t* __rest
 // (|rint(x)| <= 2^31; beyond that the cast saturates whatever the fraction is).
 typedef __attribute__((address_space(3))) void* lds_dma_ptr;
 
-template <int P>
-__device__ __forceinline__ void mirror_store_one(double x, const wfft::MirrorLane& m) {
-  if constexpr (P == 0) wfft::lds_store_f64(m.store_base0, 0, x);
-  else wfft::lds_store_f64(m.store_base, wfft::br5(P) * 256, x);
-}
-
 template <bool ACCUMULATE, bool MARGIN>
-__global__ __launch_bounds__(kBlock, 1) void polymul2_kernel(const int32_t* __restrict__ d,
-                                                             const int32_t* __restrict__ s,
-                                                             const cplx* __restrict__ tables,
-                                                             int32_t* __restrict__ out,
-                                                             double* __restrict__ margin, int B) {
+__global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __restrict__ d,
+                                                            const int32_t* __restrict__ s,
+                                                            const cplx* __restrict__ tables,
+                                                            int32_t* __restrict__ out,
+                                                            double* __restrict__ margin, int B) {
   __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
   char* lds_tables = lds + kWavesPerBlock * wfft::kWaveBytes;
   load_tables(lds_tables, tables);
   const cplx* tE = reinterpret_cast<const cplx*>(lds_tables);
-  const cplx* tw = tE + 1024;
+  const cplx* tq = tE + 1024;
   const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   char* wave_tiles = lds + wave * wfft::kWaveBytes;
-  char* stage = wave_tiles + wfft::kExchangeBytes;       // operands in, then the second mirror tile
+  char* stage = wave_tiles + wfft::kExchangeBytes;       // the operands of one pair of products
   const int stride = gridDim.x * kWavesPerBlock;
 
   // operands of pair `pair` -> stage: [d_a | d_b | s_a | s_b], 4 KiB each, coefficient order;
@@ -758,133 +709,66 @@ __global__ __launch_bounds__(kBlock, 1) void polymul2_kernel(const int32_t* __re
   for (; 2 * pair < B; pair += stride) {
     const int ia = 2 * pair, ib = 2 * pair + 1;
     const bool has_b = ib < B;
-    // Lane-derived addresses are recomputed per phase (a handful of instructions; the two
-    // forward transforms share one set) instead of being kept live, or spilled, across the loop.
+    // Lane-derived addresses are recomputed per phase (a handful of instructions) instead of
+    // being kept live, or spilled, across the loop.
     auto fresh_lane = [&]() WFFT_INLINE {
       int l = lane0;
       asm volatile("" : "+v"(l));
       return l;
     };
     double re[32], im[32];
-    int lane_keep = 0;       // the lane index the two forward transforms derive their addresses from
-    unsigned park[128];      // P, parked in accumulation registers
+    unsigned park[128];      // spectrum of d, parked in accumulation registers
     TFHE_STAMP(st, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the operands have landed
     TFHE_STAMP(st, 1);
     {
       const int lane = fresh_lane(), h = lane >> 5, q = lane & 31;
-      lane_keep = lane;
-      const int32_t* in = reinterpret_cast<const int32_t*>(stage) + q;
+      const int32_t* in = reinterpret_cast<const int32_t*>(stage) + h * kN + q;
       wfft::chunked_for32<8>([&](auto ic) WFFT_INLINE {
         constexpr int r = decltype(ic)::value;
         re[r] = (double)in[32 * r];
-        im[r] = (double)in[kN + 32 * r];
       });
       TFHE_STAMP(st, 2);
-      wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+      wfft::fwd1024_twisted_real(re, im, wave_tiles + h * wfft::kHalfBytes, tE, tq, q);
       TFHE_STAMP(st, 3);
       static_for<0, 32>([&](auto ic) WFFT_INLINE {
         constexpr int p = decltype(ic)::value;
         wfft::agpr_put_f64(re[p], park[4 * p + 0], park[4 * p + 1]);
         wfft::agpr_put_f64(im[p], park[4 * p + 2], park[4 * p + 3]);
       });
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      const int lane = lane_keep, h = lane >> 5, q = lane & 31;      // as in the first transform
-      const int32_t* in = reinterpret_cast<const int32_t*>(stage) + q;
-      constexpr double kScale = 1.0 / (4.0 * 2048.0);            // a power of two: exact
+      constexpr double kScale = 1.0 / 1024.0;                    // a power of two: exact
       wfft::chunked_for32<8>([&](auto ic) WFFT_INLINE {
         constexpr int r = decltype(ic)::value;
         re[r] = (double)in[2 * kN + 32 * r] * kScale;
-        im[r] = (double)in[3 * kN + 32 * r] * kScale;
       });
+      // this pair's operands are in registers: start the copy of the next pair's
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (2 * (pair + stride) < B) fetch(pair + stride, lane);
       TFHE_STAMP(st, 4);
-      wfft::fwd2048(re, im, wave_tiles, tE, tw, q, h);
+      wfft::fwd1024_twisted_real(re, im, wave_tiles + h * wfft::kHalfBytes, tE, tq, q);
       TFHE_STAMP(st, 5);
     }
     __builtin_amdgcn_sched_barrier(0);
-    {
-      const int lane = fresh_lane(), h = lane >> 5, q = lane & 31;
-      // Q' = (Re Q[-k], -Im Q[-k]): real parts through the first tile, imaginary parts through
-      // the second.  Step m handles the two bins of a lane whose rows are m and 31 - m: it
-      // reads their mirror values (rows 31 - m and m) and leaves W2 of both bins where the
-      // Q values stood, so that W2 never occupies registers.  The stores run one step late:
-      // lane 0 of half E, its own mirror lane, keeps its values one row lower, and its row
-      // 30 - m is read in step m + 1.  (A wavefront's LDS operations run in program order.)
-      const wfft::MirrorLane ml = wfft::mirror_lane(wave_tiles, q, h);
-      const wfft::MirrorLane ml2 = wfft::mirror_lane(stage, q, h);
-      wfft::mirror_store(re, ml);
-      wfft::mirror_store(im, ml2);
-      TFHE_STAMP(st, 6);
-      double w2r[32], w2i[32];      // W2 = S + i T of the bins of the step before
-      auto point = [&](auto pc, double qr, double qi) WFFT_INLINE {
-        constexpr int p = decltype(pc)::value;
-        const double pr = wfft::agpr_get_f64(park[4 * p + 0], park[4 * p + 1]);
-        const double pi = wfft::agpr_get_f64(park[4 * p + 2], park[4 * p + 3]);
-        const double ar = pr * re[p] - pi * im[p], ai = pr * im[p] + pi * re[p];     // A = P Q
-        const double cr = pr * qr - pi * qi, ci = pr * qi + pi * qr;                 // C = P Q'
-        const double sr = ar + cr, si = ai + ci, tr = ar - cr, ti = ai - ci;
-        double w1r = sr + ti, w1i = si - tr;               // W1 = S - i T
-        // computed here, not where it is next used: keeps S and T from staying alive instead
-        asm volatile("" : "+v"(w1r), "+v"(w1i));
-        re[p] = w1r;
-        im[p] = w1i;
-        w2r[p] = sr - ti;
-        w2i[p] = si + tr;
-      };
-      auto put = [&](auto pc) WFFT_INLINE {
-        constexpr int p = decltype(pc)::value;
-        mirror_store_one<p>(w2r[p], ml);
-        mirror_store_one<p>(w2i[p], ml2);
-      };
-      static_for<0, 16>([&](auto mc) WFFT_INLINE {
-        constexpr int m = decltype(mc)::value;
-        constexpr int pa = wfft::br5(m), pb = wfft::br5(31 - m);
-        const double qra = wfft::mirror_load<pa>(ml), qia = -wfft::mirror_load<pa>(ml2);
-        const double qrb = wfft::mirror_load<pb>(ml), qib = -wfft::mirror_load<pb>(ml2);
-        if constexpr (m > 0) {
-          put(std::integral_constant<int, wfft::br5(m - 1)>{});
-          put(std::integral_constant<int, wfft::br5(32 - m)>{});
-        }
-        point(std::integral_constant<int, pa>{}, qra, qia);
-        point(std::integral_constant<int, pb>{}, qrb, qib);
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      put(std::integral_constant<int, wfft::br5(15)>{});
-      put(std::integral_constant<int, wfft::br5(16)>{});
-      wfft::wave_lds_fence();
-      TFHE_STAMP(st, 7);
-      // Z = (W1 + W2') / 4 (the factor is in Q), W2' = (Re W2[-k], -Im W2[-k])
-      wfft::pipelined_for32<4, double>(
-          [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml); },
-          [&](auto ic, const double& m) WFFT_INLINE { re[decltype(ic)::value] += m; });
-      wfft::pipelined_for32<4, double>(
-          [&](auto ic) WFFT_INLINE { return wfft::mirror_load<decltype(ic)::value>(ml2); },
-          [&](auto ic, const double& m) WFFT_INLINE { im[decltype(ic)::value] -= m; });
-      // the second tile is free again: start the copy of the next pair's operands
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (2 * (pair + stride) < B) fetch(pair + stride, lane);
-      wfft::wave_lds_fence();
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    TFHE_STAMP(st, 8);
-    const int lane = fresh_lane(), h = lane >> 5, q = lane & 31;
-    // Inverse transform; the second half of the outputs (t >= N) is E - twist*O.
-    wfft::fft1024_inv(re, im, wave_tiles + h * wfft::kHalfBytes, tE, q);
-    wfft::twist_odd_half<true>(re, im, tE, tw, q, h);
-    const int prod = h ? ib : ia;        // half E ends with product a, half O with product b
-    const bool live = h ? has_b : true;
-    // every lane takes part in the half-wave exchange; afterwards re = coefficients t < N,
-    // im = coefficients N + t of this lane's product, t = q + 32 r
-    static_for<0, 32>([&](auto ic) WFFT_INLINE {
-      constexpr int r = decltype(ic)::value;
-      double e = re[r], o = im[r];       // e = (E: Re E | O: Im E), o = (E: Re twO | O: Im twO)
-      wfft::swap_halves(e, o);
-      re[r] = e + o;
-      im[r] = e - o;
+    wfft::chunked_for32<4>([&](auto ic) WFFT_INLINE {
+      constexpr int p = decltype(ic)::value;
+      const double pr = wfft::agpr_get_f64(park[4 * p + 0], park[4 * p + 1]);
+      const double pi = wfft::agpr_get_f64(park[4 * p + 2], park[4 * p + 3]);
+      const double qr = re[p], qi = im[p];
+      re[p] = pr * qr - pi * qi;
+      im[p] = pr * qi + pi * qr;
     });
+    __builtin_amdgcn_sched_barrier(0);
+    TFHE_STAMP(st, 7);
+    const int lane = fresh_lane(), h = lane >> 5, q = lane & 31;
+    // afterwards re = coefficients t < N, im = coefficients N + t of this lane's product,
+    // t = q + 32 r
+    wfft::inv1024_twisted_real<!ACCUMULATE>(
+        re, im, wave_tiles + h * wfft::kHalfBytes, tE, tq, q,
+        [&](auto rc, double v) WFFT_INLINE { re[decltype(rc)::value] = v; },
+        [&](auto rc, double v) WFFT_INLINE { im[decltype(rc)::value] = v; });
     TFHE_STAMP(st, 9);
+    const int prod = h ? ib : ia;        // one product per half-wave
+    const bool live = h ? has_b : true;
     if (MARGIN) {
       Margin mg;
       static_for<0, 32>([&](auto ic) WFFT_INLINE {
@@ -1630,7 +1514,7 @@ void make_tables(std::vector<cplx>& t) {
     }
   for (int r = 0; r < 32; r++)
     for (int q = 0; q < 32; q++) {
-      long double ang = -two_pi * (long double)(q + 32 * r) / 2048.0L;
+      long double ang = -two_pi * (long double)(q + 32 * r) / 4096.0L;
       t[1024 + r * 32 + q].x = (double)cosl(ang);
       t[1024 + r * 32 + q].y = (double)sinl(ang);
     }
@@ -2142,9 +2026,9 @@ int tfhe_hip_polymul_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, 
   const unsigned grid = (unsigned)std::min<size_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock,
                                                    (size_t)ctx->num_cus);
   if (accumulate)
-    hipLaunchKernelGGL((polymul2_kernel<true, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (double*)nullptr, (int)B);
+    hipLaunchKernelGGL((polymul_kernel<true, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (double*)nullptr, (int)B);
   else
-    hipLaunchKernelGGL((polymul2_kernel<false, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (double*)nullptr, (int)B);
+    hipLaunchKernelGGL((polymul_kernel<false, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (double*)nullptr, (int)B);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
@@ -2333,7 +2217,7 @@ int tfhe_hip_polymul_margin_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32
   const size_t pairs = (B + 1) / 2;
   const unsigned grid = (unsigned)std::min<size_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock,
                                                    (size_t)ctx->num_cus);
-  hipLaunchKernelGGL((polymul2_kernel<false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s,
+  hipLaunchKernelGGL((polymul_kernel<false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s,
                      ctx->tables, (int32_t*)nullptr, margin, (int)B);
   HIP_TRY(ctx, hipGetLastError());
   return 0;

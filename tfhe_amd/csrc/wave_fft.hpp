@@ -490,6 +490,63 @@ __device__ __forceinline__ void fft1024_inv(double (&re)[32], double (&im)[32], 
   dit32<true>(re, im);
 }
 
+// ---------------------------------------------------------------------------
+// Twisted 1024-point transforms: one REAL polynomial of N = 1024 coefficients per
+// half-wave.  A(k) = sum_n a[n] w4096^n w1024^(n k) is the value of a(x) at
+// z_k = w4096^(4k+1), k = 0..1023.  These 1024 points and their complex
+// conjugates are the 2048 roots of z^2048 = -i, and a real polynomial takes
+// conjugate values at conjugate points, so the 1024 values determine a real
+// polynomial of degree < 2048: the product c = a b of two real polynomials of
+// degree < 1024 has C(k) = A(k) B(k), and the unnormalised inverse transform
+// gives y[n] = 1024 (c[n] - i c[n + 1024]) w4096^n (z_k^1024 = -i).  The low half
+// of the linear convolution is Re(y[n] conj(w4096^n)) / 1024, the high half
+// -Im(...) / 1024.  No zero padding, no separation of packed spectra, and both
+// half-waves do the same useful work.
+// tq: LDS table, entry [r*32 + q] = exp(-2 pi i (q + 32 r) / 4096).
+// ---------------------------------------------------------------------------
+// x[n] in re (n = q + 32 r, natural layout) -> spectrum in the S-layout: lane q,
+// register p holds A(q + 32 br5(p)).
+__device__ __forceinline__ void fwd1024_twisted_real(double (&re)[32], double (&im)[32], char* tile,
+                                                     const cplx* tE, const cplx* tq, int q) {
+  wave_lds_fence();
+  pipelined_pairs32<WFFT_TWIST_GROUP, cplx>(
+      [&](auto ic) WFFT_INLINE { return tq[decltype(ic)::value * 32 + q]; },
+      [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
+        constexpr int r0 = decltype(i0)::value, r1 = decltype(i1)::value;
+        im[r0] = re[r0] * w0.y;
+        im[r1] = re[r1] * w1.y;
+        re[r0] = re[r0] * w0.x;
+        re[r1] = re[r1] * w1.x;
+      });
+  fft1024_fwd(re, im, tile, tE, q);
+}
+
+// Spectrum C in the S-layout -> lo(integral_constant<r>, 1024 c[t]) and, when HI,
+// hi(integral_constant<r>, 1024 c[t + 1024]) for t = q + 32 r.
+template <bool HI, class Lo, class Hi>
+__device__ __forceinline__ void inv1024_twisted_real(double (&re)[32], double (&im)[32], char* tile,
+                                                     const cplx* tE, const cplx* tq, int q, Lo&& lo,
+                                                     Hi&& hi) {
+  fft1024_inv(re, im, tile, tE, q);
+  wave_lds_fence();
+  pipelined_pairs32<WFFT_TWIST_GROUP, cplx>(
+      [&](auto ic) WFFT_INLINE { return tq[decltype(ic)::value * 32 + q]; },
+      [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
+        constexpr int r0 = decltype(i0)::value, r1 = decltype(i1)::value;
+        // y conj(w) = (yr c + yi s) + i (yi c - yr s)
+        const double l0 = re[r0] * w0.x + im[r0] * w0.y;
+        const double l1 = re[r1] * w1.x + im[r1] * w1.y;
+        if constexpr (HI) {
+          const double h0 = re[r0] * w0.y - im[r0] * w0.x;
+          const double h1 = re[r1] * w1.y - im[r1] * w1.x;
+          hi(i0, h0);
+          hi(i1, h1);
+        }
+        lo(i0, l0);
+        lo(i1, l1);
+      });
+}
+
 // Multiply the O half by the twist w2048^(q + 32 r) (CONJ: by its conjugate).
 // tw: LDS table, entry [r*32 + q] = exp(-2 pi i (q + 32 r) / 2048).  natural layout.
 template <bool CONJ>
