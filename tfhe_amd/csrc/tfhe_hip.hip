@@ -150,16 +150,18 @@ constexpr uint32_t tt_mask() {
 // polynomial h (the level-p digits of accumulator polynomial h): its twisted
 // transform D_h (wave_fft.hpp), then the two products with the key polynomials
 // of TGSW row (h, p): D_h * K_{h,h} contributes to result polynomial h, which is
-// the one this half accumulates, and D_h * K_{h,1-h} to the other half's.  Each
-// rounded coefficient is handed to accumulate(integral_constant<r>, value,
-// bool_constant<CROSS>) by lane (h, q) for coefficient t = q + 32 r; CROSS says
-// that it belongs to result polynomial 1 - h.
+// the one this half accumulates, and D_h * K_{h,1-h} to the other half's.  Lane
+// (h, q) hands coefficient t = q + 32 r of the first product to
+// acc.own(integral_constant<r>, value); the second product's coefficients, which
+// belong to result polynomial 1 - h, are rounded by acc.prepare(value) as they
+// appear and handed over together, acc.cross(int32 (&)[32]), so that an exchange
+// between the half-waves is issued for all of them at once.
 // tt: this lane's base (+ 8 q) into the [N][2] int32 sample (XORed with tt_mask).
 // bk_level: [2][32][64] cplx: block 0 holds K_{h,h}, block 1 K_{h,1-h} in lane (h, q).
 template <int BGBIT, class Acc>
 __device__ __forceinline__ void level_product(int p, const char* tt, const cplx* __restrict__ bk_level,
                                               char* wave_tiles, const cplx* tE, const cplx* tq,
-                                              int lane, Acc&& accumulate, StampCtx& st) {
+                                              int lane, Acc&& acc, StampCtx& st) {
   const int h = lane >> 5, q = lane & 31;
   char* tile = wave_tiles + h * wfft::kHalfBytes;
   double re[32], im[32];
@@ -196,7 +198,7 @@ __device__ __forceinline__ void level_product(int p, const char* tt, const cplx*
   TFHE_STAMP(st, 4);
   wfft::inv1024_twisted_real<false>(
       re, im, tile, tE, tq, q,
-      [&](auto rc, double v) WFFT_INLINE { accumulate(rc, v, std::false_type{}); }, [](auto, double) {});
+      [&](auto rc, double v) WFFT_INLINE { acc.own(rc, v); }, [](auto, double) {});
   TFHE_STAMP(st, 5);
   {
     // Z = D_h * K_{h,1-h} as D_h comes back from the accumulation registers
@@ -212,9 +214,12 @@ __device__ __forceinline__ void level_product(int p, const char* tt, const cplx*
     });
   }
   TFHE_STAMP(st, 6);
+  int32_t other[32];
   wfft::inv1024_twisted_real<false>(
       re, im, tile, tE, tq, q,
-      [&](auto rc, double v) WFFT_INLINE { accumulate(rc, v, std::true_type{}); }, [](auto, double) {});
+      [&](auto rc, double v) WFFT_INLINE { other[decltype(rc)::value] = acc.prepare(v); },
+      [](auto, double) {});
+  acc.cross(other);
   TFHE_STAMP(st, 7);
 }
 
@@ -231,20 +236,57 @@ struct Margin {
   }
 };
 
+// Sinks of level_product.  RegisterSink: wrapping adds of rounded, saturated products
+// (numerics.rs:138-155) into the accumulator a wavefront keeps in accumulation registers;
+// the products for the other half-wave's polynomial cross over with ds_bpermute.
+template <class M>
+struct RegisterSink {
+  unsigned (&acc_a)[32];
+  M& margin;
+  int partner;        // the other half-wave's lane, as a ds_bpermute address
+  __device__ __forceinline__ int32_t prepare(double v) {
+    margin.track(v);
+    return wfft::round_sat_i32(v);
+  }
+  template <class RC>
+  __device__ __forceinline__ void own(RC, double v) {
+    constexpr int r = RC::value;
+    acc_a[r] = acc_put((unsigned)wadd((int32_t)acc_get(acc_a[r]), prepare(v)));
+  }
+  __device__ __forceinline__ void cross(int32_t (&x)[32]) {
+    static_for<0, 32>([&](auto ic) WFFT_INLINE {
+      constexpr int r = decltype(ic)::value;
+      x[r] = __builtin_amdgcn_ds_bpermute(partner, x[r]);
+    });
+    static_for<0, 32>([&](auto ic) WFFT_INLINE {
+      constexpr int r = decltype(ic)::value;
+      acc_a[r] = acc_put((unsigned)wadd((int32_t)acc_get(acc_a[r]), x[r]));
+    });
+  }
+};
+// LdsSink: the same adds into an accumulator [2][N] shared by a workgroup in LDS.
+struct LdsSink {
+  unsigned* accL;
+  int h, q;
+  __device__ __forceinline__ int32_t prepare(double v) { return wfft::round_sat_i32(v); }
+  template <class RC>
+  __device__ __forceinline__ void own(RC, double v) {
+    atomicAdd(accL + h * kN + q + 32 * RC::value, (unsigned)prepare(v));
+  }
+  __device__ __forceinline__ void cross(int32_t (&x)[32]) {     // result polynomial 1 - h
+    static_for<0, 32>([&](auto ic) WFFT_INLINE {
+      constexpr int r = decltype(ic)::value;
+      atomicAdd(accL + (1 - h) * kN + q + 32 * r, (unsigned)x[r]);
+    });
+  }
+};
+
 template <int L, int BGBIT, class M = NoMargin>
 __device__ __forceinline__ void extprod_accumulate(unsigned (&acc_a)[32], const cplx* __restrict__ bk,
                                                    char* wave_lds, const cplx* tE, const cplx* tq,
                                                    int lane, StampCtx& st, M&& margin = M{}) {
   const char* tt = wave_lds + kTtOff + (lane & 31) * 8;
-  // the other half-wave's lane, as a ds_bpermute address
-  const int partner = (lane ^ 32) << 2;
-  auto accumulate = [&](auto rc, double v, auto cross) WFFT_INLINE {
-    constexpr int r = decltype(rc)::value;
-    margin.track(v);
-    int32_t x = wfft::round_sat_i32(v);
-    if constexpr (decltype(cross)::value) x = __builtin_amdgcn_ds_bpermute(partner, x);
-    acc_a[r] = acc_put((unsigned)wadd((int32_t)acc_get(acc_a[r]), x));
-  };
+  RegisterSink<std::remove_reference_t<M>> accumulate{acc_a, margin, (lane ^ 32) << 2};
 #pragma unroll 1
   for (int p = 0; p < L; p++)
     level_product<BGBIT>(p, tt, bk + (size_t)p * 2 * 2048, wave_lds, tE, tq, lane, accumulate, st);
@@ -465,12 +507,7 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
   const int decal = 32 - (p + 1) * BGBIT;
   StampCtx st;
   // wrapping add of a rounded, saturated product (numerics.rs:138-155)
-  // (CROSS: the product belongs to the result polynomial of the other half-wave)
-  auto accumulate = [&](auto rc, double v, auto cross) WFFT_INLINE {
-    constexpr int r = decltype(rc)::value;
-    const int poly = decltype(cross)::value ? 1 - h : h;
-    atomicAdd(reinterpret_cast<unsigned*>(accL) + poly * kN + q + 32 * r, (unsigned)wfft::round_sat_i32(v));
-  };
+  LdsSink accumulate{reinterpret_cast<unsigned*>(accL), h, q};      // CPW == 2: level_product
 
   for (int x = threadIdx.x; x < 2 * kN; x += 64 * W) {
     prevL[x] = 0;                                              // bootstrapping.rs:116-117

@@ -65,8 +65,8 @@ else:
     if which == "batch":
         # the wavefront that reports has finished three ciphertexts of 500 iterations
         print("blind_rotate_kernel, per iteration (two levels)")
-        show({8: "loop, abar", 0: "rotate", 1: "digits", 2: "forward", 3: "key prologue, mirror re", 4: "mirror, product 0",
-              5: "inverse 0", 6: "unpark, product 1", 7: "inverse 1"}, st, 1500)
+        show({8: "loop, abar", 0: "rotate", 1: "digits", 2: "forward", 4: "park, product A",
+              5: "inverse A", 6: "unpark, product B", 7: "inverse B"}, st, 1500)
     else:
         print("blind_rotate_split_kernel (one ciphertext), wavefront 0, per iteration")
         show(dict(enumerate(["barrier (acc complete)", "rotate", "barrier (tt complete)", "prev, digits", "forward",
