@@ -36,7 +36,7 @@
 #define WFFT_TW_GROUP 8
 #endif
 #ifndef WFFT_TWIST_GROUP
-#define WFFT_TWIST_GROUP 4
+#define WFFT_TWIST_GROUP 8
 #endif
 // 1: the twist of the odd half-wave runs without a branch (the even half
 // multiplies by 1); 0: under a branch on the half.
@@ -365,11 +365,12 @@ __device__ __forceinline__ void dif32(double (&re)[32], double (&im)[32]) {
 
 // Forward 32-point transform, natural in -> S-layout out: decimation in
 // frequency (0), or decimation in time on the bit-reversed register view (1; same
-// layouts, 68 fewer instructions per pass, but its chained multiply-adds leave the
-// single wavefront of a SIMD with longer dependency stalls: measured 2 % slower
-// in the blind rotation on MI355X).
+// layouts, 68 fewer instructions per pass thanks to the six-FMA butterflies).  With
+// the twisted transforms (1) is 3 % faster in the blind rotation on MI355X; with the
+// zero-padded form this file had before, whose register pressure was higher, it was
+// 2 % slower.
 #ifndef WFFT_FWD_DIT
-#define WFFT_FWD_DIT 0
+#define WFFT_FWD_DIT 1
 #endif
 __device__ __forceinline__ void fwd32(double (&re)[32], double (&im)[32]) {
 #if WFFT_FWD_DIT
