@@ -59,13 +59,24 @@ struct StampCtx {
 #ifndef TFHE_K0_DEPTH
 #define TFHE_K0_DEPTH 3
 #endif
-#ifndef TFHE_MIRROR_GROUP
-#define TFHE_MIRROR_GROUP 8
+// The first loads of a level's first key block are issued before (1) or after (0) the
+// forward transform.
+#ifndef TFHE_K0_EARLY
+#define TFHE_K0_EARLY 0
 #endif
 #ifndef TFHE_K1_DEPTH
 #define TFHE_K1_DEPTH 2
 #endif
 
+
+// Low-latency kernel: the first loads of a wavefront's key column are issued before the
+// forward transform (1) or after it (0); depth of their software pipeline in groups of four.
+#ifndef TFHE_SPLIT_EARLY_KEY
+#define TFHE_SPLIT_EARLY_KEY 1
+#endif
+#ifndef TFHE_SPLIT_KEY_DEPTH
+#define TFHE_SPLIT_KEY_DEPTH 3
+#endif
 
 // Where the accumulator of the blind rotation lives between uses: parked in
 // accumulation registers by hand (0) or left to the register allocator (1, which
@@ -177,16 +188,22 @@ __device__ __forceinline__ void level_product(int p, const char* tt, const cplx*
     re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t, decal, BGBIT);
   });
   TFHE_STAMP(st, 1);
-  wfft::fwd1024_twisted_real(re, im, tile, tE, tq, q);
-  TFHE_STAMP(st, 2);
   const cplx* b0 = bk_level + lane;
   const cplx* b1 = bk_level + 2048 + lane;
   auto load_k0 = [&](auto ic) WFFT_INLINE { return b0[decltype(ic)::value * 64]; };
   auto load_k1 = [&](auto ic) WFFT_INLINE { return b1[decltype(ic)::value * 64]; };
+  wfft::Pipe32<4, TFHE_K0_DEPTH, cplx> k0p;
+#if TFHE_K0_EARLY
+  k0p.prologue(load_k0);
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  wfft::fwd1024_twisted_real(re, im, tile, tE, tq, q);
+  TFHE_STAMP(st, 2);
   {
     // Z = D_h * K_{h,h} in place; a copy of D_h is parked for the second product
-    wfft::Pipe32<4, TFHE_K0_DEPTH, cplx> k0p;
+#if !TFHE_K0_EARLY
     k0p.prologue(load_k0);
+#endif
     k0p.run2(load_k0, [&](auto i0, const cplx& ka, auto i1, const cplx& kb) WFFT_INLINE {
       constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;
       wfft::agpr_put_f64(re[s0], hold[4 * s0 + 0], hold[4 * s0 + 1]);
@@ -569,13 +586,20 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
       re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t, decal, BGBIT);
     });
     TFHE_STAMP(st, 3);
-    wfft::fwd1024_twisted_real(re, im, tile, tE, tq, q);
-    TFHE_STAMP(st, 4);
-    // K_{h,u}: block 0 of the level holds K_{h,h}, block 1 K_{h,1-h}
+    // K_{h,u}: block 0 of the level holds K_{h,h}, block 1 K_{h,1-h}; the first loads are
+    // issued before the forward transform (a single ciphertext's key comes from HBM)
     const cplx* kcol = args.bkfft + ((size_t)i * L + p) * 2 * 2048 + (h == u ? 0 : 2048) + lane;
     auto load_k = [&](auto ic) WFFT_INLINE { return kcol[decltype(ic)::value * 64]; };
-    wfft::Pipe32<4, 3, cplx> kp;
+    wfft::Pipe32<4, TFHE_SPLIT_KEY_DEPTH, cplx> kp;
+#if TFHE_SPLIT_EARLY_KEY
     kp.prologue(load_k);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    wfft::fwd1024_twisted_real(re, im, tile, tE, tq, q);
+    TFHE_STAMP(st, 4);
+#if !TFHE_SPLIT_EARLY_KEY
+    kp.prologue(load_k);
+#endif
     TFHE_STAMP(st, 5);
     kp.run2(load_k, [&](auto i0, const cplx& ka, auto i1, const cplx& kb) WFFT_INLINE {
       constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;

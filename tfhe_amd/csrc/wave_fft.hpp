@@ -1,8 +1,7 @@
 // wave_fft.hpp — f64 FFT machinery for one 64-lane wavefront on gfx950.
 //
-// A zero-padded 2048-point transform is computed by ONE wavefront as two
-// 1024-point transforms, one per half-wave: lanes 0-31 ("half E") own the even
-// bins, lanes 32-63 ("half O") the odd bins.  Inside a half, element
+// A half-wave (32 lanes) owns one 1024-point complex transform; the two halves of
+// a wavefront run two independent transforms in the same instructions.  Element
 // n = q + 32*r of a 1024-point sequence lives in lane q, register r, and the
 // 1024-point DFT is the four-step 32 x 32 decomposition:
 //
@@ -15,15 +14,20 @@
 // 8 KiB tile, which halves the exchange area (the other half of a wavefront's
 // LDS share holds per-ciphertext state of the caller).
 //
+// Products of real polynomials use the TWISTED transform on top of it
+// (fwd1024_twisted_real / inv1024_twisted_real): the values of a polynomial at
+// the 1024 points w4096^(4k+1), which determine a real polynomial of degree
+// < 2048, so a linear convolution of two polynomials of 1024 coefficients needs
+// no zero padding and one 1024-point transform per polynomial.
+//
 // No workgroup barrier is used anywhere: every exchange is between lanes of
 // the same wavefront, whose LDS operations execute in program order.
 //
 // Register-index conventions (br = 5-bit bit reversal):
 //   "natural"  : register r holds element q + 32*r
 //   "S-layout" : register p holds element q + 32*br(p)   (spectra are kept so)
-// Forward transforms go natural -> S-layout (two decimation-in-frequency
-// passes), inverse transforms go S-layout -> natural (two decimation-in-time
-// passes), so no explicit reordering is ever executed.
+// Forward transforms go natural -> S-layout, inverse transforms S-layout ->
+// natural, so no explicit reordering is ever executed.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -38,8 +42,6 @@
 #ifndef WFFT_TWIST_GROUP
 #define WFFT_TWIST_GROUP 8
 #endif
-// 1: the twist of the odd half-wave runs without a branch (the even half
-// multiplies by 1); 0: under a branch on the half.
 // Scheduling fences: between the groups of a software pipeline (1/0), and
 // every WFFT_TAIL_CHUNK elements of the inverse transform's element-wise tail
 // (0 = none).
@@ -55,9 +57,6 @@
 #endif
 #ifndef WFFT_ASM_DIT
 #define WFFT_ASM_DIT 1
-#endif
-#ifndef WFFT_TWIST_BRANCHFREE
-#define WFFT_TWIST_BRANCHFREE 0
 #endif
 
 namespace wfft {
@@ -546,130 +545,6 @@ __device__ __forceinline__ void inv1024_twisted_real(double (&re)[32], double (&
         lo(i0, l0);
         lo(i1, l1);
       });
-}
-
-// Multiply the O half by the twist w2048^(q + 32 r) (CONJ: by its conjugate).
-// tw: LDS table, entry [r*32 + q] = exp(-2 pi i (q + 32 r) / 2048).  natural layout.
-template <bool CONJ>
-__device__ __forceinline__ void twist_odd_half(double (&re)[32], double (&im)[32], const cplx* tE,
-                                               const cplx* tw, int q, int h) {
-  auto mul = [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
-    constexpr int r0 = decltype(i0)::value, r1 = decltype(i1)::value;
-    cmul2<CONJ>(re[r0], im[r0], w0, re[r1], im[r1], w1);
-  };
-#if WFFT_TWIST_BRANCHFREE
-  // The E half multiplies by 1, read from column 0 of tE (tE[r*32] = w1024^0);
-  // x * (1 + 0i) is exact.
-  const cplx* w_lane = h ? tw + q : tE;
-  pipelined_pairs32<WFFT_TWIST_GROUP, cplx>(
-      [&](auto ic) WFFT_INLINE { return w_lane[decltype(ic)::value * 32]; }, mul);
-#else
-  (void)tE;
-  if (h) {
-    pipelined_pairs32<WFFT_TWIST_GROUP, cplx>(
-        [&](auto ic) WFFT_INLINE { return tw[decltype(ic)::value * 32 + q]; }, mul);
-  }
-#endif
-}
-
-// Zero-padded 2048-point forward transform of c[n] = re + i im (n < 1024),
-// natural layout in BOTH halves on entry (each half holds the same data).
-// On exit lane (h, q), register p holds bin k = 2*(q + 32*br5(p)) + h.
-__device__ __forceinline__ void fwd2048(double (&re)[32], double (&im)[32], char* wave_tiles,
-                                        const cplx* tE, const cplx* tw, int q, int h) {
-  twist_odd_half<false>(re, im, tE, tw, q, h);
-  fft1024_fwd(re, im, wave_tiles + h * kHalfBytes, tE, q);
-}
-
-// Half-wave exchange without selects.  With a = (E: aE | O: aO) and
-// b = (E: bE | O: bO) on entry, on exit a = (E: aE | O: bE), b = (E: aO | O: bO):
-// one v_permlane32_swap_b32 per dword swaps a's upper lanes with b's lower lanes.
-__device__ __forceinline__ void swap_halves_u32(unsigned& a, unsigned& b) {
-#if __has_builtin(__builtin_amdgcn_permlane32_swap)
-  auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-  a = r[0];
-  b = r[1];
-#else
-  const bool up = (threadIdx.x & 32) != 0;
-  const unsigned a2 = __shfl_xor(a, 32, 64), b2 = __shfl_xor(b, 32, 64);
-  const unsigned na = up ? b2 : a, nb = up ? b : a2;
-  a = na;
-  b = nb;
-#endif
-}
-__device__ __forceinline__ void swap_halves(double& a, double& b) {
-  const unsigned long long ua = (unsigned long long)__double_as_longlong(a);
-  const unsigned long long ub = (unsigned long long)__double_as_longlong(b);
-  unsigned alo = (unsigned)ua, ahi = (unsigned)(ua >> 32), blo = (unsigned)ub, bhi = (unsigned)(ub >> 32);
-  swap_halves_u32(alo, blo);
-  swap_halves_u32(ahi, bhi);
-  a = __longlong_as_double((long long)(((unsigned long long)ahi << 32) | alo));
-  b = __longlong_as_double((long long)(((unsigned long long)bhi << 32) | blo));
-}
-
-// First 1024 outputs of the unnormalised inverse 2048-point transform of a
-// spectrum in the layout fwd2048 produces.  On exit lane (h, q), register r
-// holds, for t = q + 32 r: the REAL part of x[t] when h == 0, the IMAGINARY
-// part when h == 1; each value is handed to sink(integral_constant<r>, value).
-// mid() runs between the transform proper and the element-wise tail (a place
-// with few live registers, for the caller to start loads of its next phase).
-template <class Sink, class Mid>
-__device__ __forceinline__ void inv2048_first_half(double (&re)[32], double (&im)[32],
-                                                   char* wave_tiles, const cplx* tE,
-                                                   const cplx* tw, int q, int h, Sink&& sink,
-                                                   Mid&& mid) {
-  fft1024_inv(re, im, wave_tiles + h * kHalfBytes, tE, q);
-  mid();
-  twist_odd_half<true>(re, im, tE, tw, q, h);
-  auto tail = [&](auto ic) WFFT_INLINE {
-    constexpr int r = decltype(ic)::value;
-    // (E: Re E | O: Im E) + (E: Re twO | O: Im twO)
-    double a = re[r], b = im[r];
-    swap_halves(a, b);
-    sink(ic, a + b);
-  };
-#if WFFT_TAIL_CHUNK
-  chunked_for32<WFFT_TAIL_CHUNK>(tail);
-#else
-  static_for<0, 32>(tail);
-#endif
-}
-
-// Mirror exchange of one f64 per bin.  A spectrum in fwd2048's layout has bin
-// k = 2*(q + 32*ka) + h in lane (h, q), register p with ka = br5(p); its mirror
-// image -k mod 2048 lives in the same half, at lane q2 = (32 - q) & 31 (h = 0)
-// or 31 - q (h = 1) and ka' = 31 - ka, except for lane 0 of half E, which is its
-// own mirror lane with ka' = (32 - ka) & 31.  mirror_store writes register p to
-// row ka of the lane's column; lane 0 of half E writes one row lower (ka = 0 to
-// row 31), so that every lane finds its mirror value at row 31 - ka of column
-// q2: all loads and all but one store are a per-lane base plus a constant.
-struct MirrorLane {
-  char* store_base;     // rows ka >= 1
-  char* store_base0;    // row of ka = 0
-  const char* load_base;
-};
-__device__ __forceinline__ MirrorLane mirror_lane(char* wave_tiles, int q, int h) {
-  MirrorLane m;
-  char* tile = wave_tiles + h * kHalfBytes;
-  const bool own_mirror = (h == 0) && (q == 0);
-  m.store_base = tile + q * 8 - (own_mirror ? 256 : 0);
-  m.store_base0 = tile + q * 8 + (own_mirror ? 31 * 256 : 0);
-  const int q2 = h ? (31 - q) : ((32 - q) & 31);
-  m.load_base = tile + q2 * 8;
-  return m;
-}
-__device__ __forceinline__ void mirror_store(const double (&v)[32], const MirrorLane& m) {
-  wave_lds_fence();
-  lds_store_f64(m.store_base0, 0, v[0]);
-  static_for<1, 32>([&](auto ic) WFFT_INLINE {
-    constexpr int p = decltype(ic)::value;
-    lds_store_f64(m.store_base, br5(p) * 256, v[p]);
-  });
-  wave_lds_fence();
-}
-template <int P>
-__device__ __forceinline__ double mirror_load(const MirrorLane& m) {
-  return lds_load_f64(m.load_base, (31 - br5(P)) * 256);
 }
 
 // Explicit parking of long-lived values in the accumulation registers (AGPRs).

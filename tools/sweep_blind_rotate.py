@@ -3,7 +3,7 @@ sizes, scheduler strategy, asm/C++ butterflies) as tools/_sweep/lib<name>.so, in
 lists those without scratch memory in tools/_sweep/names.txt.  On the GPU box each variant is
 then timed with
     TFHE_HIP_LIB=tools/_sweep/lib<name>.so python bench.py --steps 3 --no-cpu-baseline --no-latency --no-bit128
-(the sweep of this round: gpurun_out/sweep2.txt, summarised in profiles/r02_sweep_blind_rotate.txt).
+by tools/sweep_run.sh (results of this round: profiles/r02_sweep_blind_rotate*.txt).
 """
 import os
 import re
@@ -12,12 +12,11 @@ from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tools", "_sweep")
-base = dict(TWG=8, TWISTG=4, K0D=4, K1D=4, MG=8, PB=1, TC=0, DIF=0, DIT=1, FD=0, ACC=0, BF=0, S="max-ilp")
-singles = [dict(TWG=4), dict(TWG=16), dict(TWISTG=2), dict(TWISTG=8), dict(K0D=3), dict(K0D=5), dict(K1D=3),
-           dict(K1D=5), dict(K1D=6), dict(MG=4), dict(MG=16), dict(PB=0), dict(TC=4), dict(TC=8), dict(TC=16),
-           dict(DIF=1), dict(DIT=0), dict(FD=1), dict(ACC=1), dict(BF=1), dict(S="default"),
-           dict(S="max-memory-clause"), dict(FD=1, ACC=1), dict(TC=8, PB=0), dict(K0D=5, K1D=5),
-           dict(TWG=16, TWISTG=8), dict(FD=1, TC=8), dict(DIF=1, TC=8), dict(MG=16, K0D=5), dict(TWISTG=8, TC=8)]
+base = dict(TWG=8, TWISTG=8, K0D=3, K1D=2, PB=1, TC=0, DIF=0, DIT=1, FD=1, ACC=1, S="max-ilp")
+singles = [dict(TWG=4), dict(TWG=16), dict(TWISTG=4), dict(TWISTG=16), dict(K0D=2), dict(K0D=4), dict(K1D=1),
+           dict(K1D=3), dict(K1D=4), dict(PB=0), dict(TC=4), dict(TC=8), dict(TC=16), dict(DIF=1), dict(DIT=0),
+           dict(FD=0), dict(ACC=0), dict(S="default"), dict(S="max-memory-clause"), dict(FD=0, ACC=0),
+           dict(TC=8, PB=0), dict(K0D=4, K1D=4), dict(TWG=16, TWISTG=16), dict(K0D=2, K1D=2), dict(TWISTG=16, TC=8)]
 variants = [dict(base)] + [dict(base, **e) for e in singles]
 
 
@@ -29,9 +28,9 @@ def name(d):
 def build(d):
     n = name(d)
     flags = [f"-DWFFT_TW_GROUP={d['TWG']}", f"-DWFFT_TWIST_GROUP={d['TWISTG']}", f"-DTFHE_K0_DEPTH={d['K0D']}",
-             f"-DTFHE_K1_DEPTH={d['K1D']}", f"-DTFHE_MIRROR_GROUP={d['MG']}", f"-DWFFT_PIPE_BARRIER={d['PB']}",
+             f"-DTFHE_K1_DEPTH={d['K1D']}", f"-DWFFT_PIPE_BARRIER={d['PB']}",
              f"-DWFFT_TAIL_CHUNK={d['TC']}", f"-DWFFT_ASM_DIF={d['DIF']}", f"-DWFFT_ASM_DIT={d['DIT']}",
-             f"-DWFFT_FWD_DIT={d['FD']}", f"-DTFHE_ACC_VGPR={d['ACC']}", f"-DWFFT_TWIST_BRANCHFREE={d['BF']}"]
+             f"-DWFFT_FWD_DIT={d['FD']}", f"-DTFHE_ACC_VGPR={d['ACC']}"]
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-c", "--offload-arch=gfx950"] + flags
     if d["S"] != "default":
         cmd += ["-mllvm", f"-amdgpu-sched-strategy={d['S']}"]
