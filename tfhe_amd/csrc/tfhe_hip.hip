@@ -1568,6 +1568,18 @@ using tfhe_detail::need_keys;
 void make_tables(std::vector<cplx>& t) {
   t.resize(2048);
   const long double two_pi = 6.283185307179586476925286766559L;
+#if WFFT_SCALAR_TWIST
+  // forward [kb][q] = w1024^(q kb) w4096^q; inverse [n1][kb] = w1024^(n1 kb) w4096^n1 (used conjugated)
+  for (int a = 0; a < 32; a++)
+    for (int b = 0; b < 32; b++) {
+      long double f = -two_pi * ((long double)(a * b) / 1024.0L + (long double)b / 4096.0L);
+      long double g = -two_pi * ((long double)(a * b) / 1024.0L + (long double)a / 4096.0L);
+      t[a * 32 + b].x = (double)cosl(f);
+      t[a * 32 + b].y = (double)sinl(f);
+      t[1024 + a * 32 + b].x = (double)cosl(g);
+      t[1024 + a * 32 + b].y = (double)sinl(g);
+    }
+#else
   for (int kb = 0; kb < 32; kb++)
     for (int q = 0; q < 32; q++) {
       long double ang = -two_pi * (long double)(q * kb) / 1024.0L;
@@ -1580,6 +1592,16 @@ void make_tables(std::vector<cplx>& t) {
       t[1024 + r * 32 + q].x = (double)cosl(ang);
       t[1024 + r * 32 + q].y = (double)sinl(ang);
     }
+#endif
+}
+
+// (cos, -sin)(2 pi r / 128) for wfft::g_w128
+void make_w128(double (&w)[64]) {
+  const long double two_pi = 6.283185307179586476925286766559L;
+  for (int r = 0; r < 32; r++) {
+    w[2 * r] = (double)cosl(-two_pi * (long double)r / 128.0L);
+    w[2 * r + 1] = (double)sinl(-two_pi * (long double)r / 128.0L);
+  }
 }
 
 
@@ -1674,6 +1696,13 @@ int tfhe_hip_create(tfhe_hip_ctx** out, int device) {
   }
   std::vector<cplx> t;
   make_tables(t);
+  // this device's copy of the twist factors; every context of a device writes the same bytes
+  double w128[64];
+  make_w128(w128);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(wfft::g_w128), w128, sizeof(w128)) != hipSuccess) {
+    delete ctx;
+    return TFHE_HIP_ERR_RUNTIME;
+  }
   if (hipMalloc((void**)&ctx->tables, t.size() * sizeof(cplx)) != hipSuccess ||
       hipMemcpy(ctx->tables, t.data(), t.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) {
     delete ctx;

@@ -59,7 +59,32 @@
 #define WFFT_ASM_DIT 1
 #endif
 
+// 1: the register part of the twist w4096^n (n = q + 32 r -> w128^r) is read with scalar loads
+// from the constant segment and the lane part w4096^q is folded into the inter-pass twiddle
+// tables; 0: the whole twist comes from a table in LDS.  WFFT_SCALAR_GROUP registers share one
+// scalar load (4 -> s_load_dwordx16; 2 and 8 measured slower, 8 through scalar register spills).
+#ifndef WFFT_SCALAR_TWIST
+#define WFFT_SCALAR_TWIST 1
+#endif
+
 namespace wfft {
+
+// (cos, -sin)(2 pi r / 128), r = 0..31; written by the host when a context is created
+__constant__ double g_w128[64];
+
+#ifndef WFFT_SCALAR_GROUP
+#define WFFT_SCALAR_GROUP 4
+#endif
+
+// The same address in a scalar register the optimiser cannot see through, so that the loads
+// from it stay where they are written instead of being hoisted out of the enclosing loop
+// (all 64 values live at once do not fit the scalar register file).
+typedef const double __attribute__((address_space(4))) * const_seg_ptr;
+__device__ __forceinline__ const_seg_ptr opaque_const(const double* table) {
+  const_seg_ptr p = (const_seg_ptr)table;
+  asm volatile("" : "+s"(p));
+  return p;
+}
 
 constexpr int kN = 1024;           // polynomial size
 constexpr int kHalfBytes = 8192;       // one 32x32 f64 tile (real OR imaginary parts of a half-wave)
@@ -502,12 +527,35 @@ __device__ __forceinline__ void fft1024_inv(double (&re)[32], double (&im)[32], 
 // of the linear convolution is Re(y[n] conj(w4096^n)) / 1024, the high half
 // -Im(...) / 1024.  No zero padding, no separation of packed spectra, and both
 // half-waves do the same useful work.
-// tq: LDS table, entry [r*32 + q] = exp(-2 pi i (q + 32 r) / 4096).
+// The twist w4096^n, n = q + 32 r, splits into a lane part w4096^q and a register
+// part w128^r.  With WFFT_SCALAR_TWIST the register part is 32 wave-uniform
+// factors read by scalar loads from g_w128 and the lane part is folded into the
+// inter-pass twiddles, which need one table per direction:
+//   tE[kb*32 + q]  = w1024^(q kb) w4096^q    (forward)
+//   tq[n1*32 + kb] = w1024^(n1 kb) w4096^n1  (inverse, used conjugated)
+// Without it tE[kb*32 + q] = w1024^(q kb) serves both directions and
+// tq[r*32 + q] = w4096^(q + 32 r) is the whole twist, read from LDS: 96 more
+// ds_read_b128 per decomposition level, which cost the blind rotation 3 % (Bit80) to
+// 7 % (Bit128) on MI355X.
 // ---------------------------------------------------------------------------
 // x[n] in re (n = q + 32 r, natural layout) -> spectrum in the S-layout: lane q,
 // register p holds A(q + 32 br5(p)).
 __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[32], double (&im)[32], char* tile,
                                                      const cplx* tE, const cplx* tq, int q) {
+#if WFFT_SCALAR_TWIST
+  // w4096^(q + 32 r) = w4096^q w128^r: the register part comes from the constant segment
+  // (scalar loads, no LDS traffic), the lane part is folded into the inter-pass twiddle tE
+  (void)tq;
+  static_for<0, 32 / WFFT_SCALAR_GROUP>([&](auto gc) WFFT_INLINE {
+    const_seg_ptr g = opaque_const(g_w128);
+    static_for<0, WFFT_SCALAR_GROUP>([&](auto ic) WFFT_INLINE {
+      constexpr int r = decltype(gc)::value * WFFT_SCALAR_GROUP + decltype(ic)::value;
+      const double c = g[2 * r], s = g[2 * r + 1];
+      im[r] = re[r] * s;
+      re[r] = re[r] * c;
+    });
+  });
+#else
   wave_lds_fence();
   pipelined_pairs32<WFFT_TWIST_GROUP, cplx>(
       [&](auto ic) WFFT_INLINE { return tq[decltype(ic)::value * 32 + q]; },
@@ -518,6 +566,7 @@ __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[32], double (&
         re[r0] = re[r0] * w0.x;
         re[r1] = re[r1] * w1.x;
       });
+#endif
   fft1024_fwd(re, im, tile, tE, q);
 }
 
@@ -527,6 +576,22 @@ template <bool HI, class Lo, class Hi>
 __device__ __forceinline__ void inv1024_twisted_real(double (&re)[32], double (&im)[32], char* tile,
                                                      const cplx* tE, const cplx* tq, int q, Lo&& lo,
                                                      Hi&& hi) {
+#if WFFT_SCALAR_TWIST
+  // tq is the inverse's inter-pass table here (conjugated lane part of the twist folded in)
+  (void)tE;
+  fft1024_inv(re, im, tile, tq, q);
+  static_for<0, 32 / WFFT_SCALAR_GROUP>([&](auto gc) WFFT_INLINE {
+    const_seg_ptr g = opaque_const(g_w128);
+    static_for<0, WFFT_SCALAR_GROUP>([&](auto ic) WFFT_INLINE {
+      constexpr int r = decltype(gc)::value * WFFT_SCALAR_GROUP + decltype(ic)::value;
+      const std::integral_constant<int, r> rc;
+      const double c = g[2 * r], s = g[2 * r + 1];
+      const double l = re[r] * c + im[r] * s;          // y conj(w128^r)
+      if constexpr (HI) hi(rc, re[r] * s - im[r] * c);
+      lo(rc, l);
+    });
+  });
+#else
   fft1024_inv(re, im, tile, tE, q);
   wave_lds_fence();
   pipelined_pairs32<WFFT_TWIST_GROUP, cplx>(
@@ -545,6 +610,7 @@ __device__ __forceinline__ void inv1024_twisted_real(double (&re)[32], double (&
         lo(i0, l0);
         lo(i1, l1);
       });
+#endif
 }
 
 // Explicit parking of long-lived values in the accumulation registers (AGPRs).
