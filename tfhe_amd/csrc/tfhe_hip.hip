@@ -120,8 +120,8 @@ __device__ __forceinline__ MonomialPower monomial_power(int power) {
   return {power % kN, ((power / kN) & 1) != 0};
 }
 
-// Copies the two twiddle tables (tE = w1024^(q kb), then tq = w4096^n, 1024 entries each)
-// into LDS.
+// Copies the two twiddle tables (make_tables: the inter-pass twiddles of the forward and of
+// the inverse transform, 1024 entries each) into LDS.
 __device__ __forceinline__ void load_tables(char* lds_tables, const cplx* __restrict__ tables) {
   cplx* dst = reinterpret_cast<cplx*>(lds_tables);
   for (int i = threadIdx.x; i < 2048; i += blockDim.x) dst[i] = tables[i];
@@ -406,7 +406,7 @@ struct BlindRotateArgs {
   const int32_t* bara;      // [B][n]   mod-switched mask (src/bootstrapping.rs:51-55)
   const int32_t* barb;      // [B]      mod-switched body (bootstrap mode)
   const cplx* bkfft;        // [n][l][2][32][64]
-  const cplx* tables;       // tE[1024], twist[1024]
+  const cplx* tables;       // make_tables: forward[1024], inverse[1024]
   int32_t* acc_io;          // hook mode: [B][3][N] accumulators, updated in place
   int32_t* out_a;           // bootstrap mode: [B][N] extracted mask
   int32_t* out_b;           // bootstrap mode: [B]
