@@ -59,9 +59,10 @@
 #define WFFT_ASM_DIT 1
 #endif
 
-// 1: the register part of the twist w4096^n (n = q + 32 r -> w128^r) is read with scalar loads
-// from the constant segment and the lane part w4096^q is folded into the inter-pass twiddle
-// tables; 0: the whole twist comes from a table in LDS.  WFFT_SCALAR_GROUP registers share one
+// Default of the twisted transforms' SCALAR parameter.  1: the register part of the twist
+// w4096^n (n = q + 32 r -> w128^r) is read with scalar loads from the constant segment and the
+// lane part w4096^q is folded into the inter-pass twiddle tables; 0: the whole twist comes from
+// a table in LDS.  WFFT_SCALAR_GROUP registers share one
 // scalar load (4 -> s_load_dwordx16; 2 and 8 measured slower, 8 through scalar register spills).
 #ifndef WFFT_SCALAR_TWIST
 #define WFFT_SCALAR_TWIST 1
@@ -528,21 +529,24 @@ __device__ __forceinline__ void fft1024_inv(double (&re)[32], double (&im)[32], 
 // -Im(...) / 1024.  No zero padding, no separation of packed spectra, and both
 // half-waves do the same useful work.
 // The twist w4096^n, n = q + 32 r, splits into a lane part w4096^q and a register
-// part w128^r.  With WFFT_SCALAR_TWIST the register part is 32 wave-uniform
+// part w128^r.  With SCALAR the register part is 32 wave-uniform
 // factors read by scalar loads from g_w128 and the lane part is folded into the
 // inter-pass twiddles, which need one table per direction:
 //   tE[kb*32 + q]  = w1024^(q kb) w4096^q    (forward)
 //   tq[n1*32 + kb] = w1024^(n1 kb) w4096^n1  (inverse, used conjugated)
 // Without it tE[kb*32 + q] = w1024^(q kb) serves both directions and
 // tq[r*32 + q] = w4096^(q + 32 r) is the whole twist, read from LDS: 96 more
-// ds_read_b128 per decomposition level, which cost the blind rotation 3 % (Bit80) to
-// 7 % (Bit128) on MI355X.
+// ds_read_b128 per decomposition level, which cost the one-wavefront-per-ciphertext
+// blind rotation 3 % (Bit80) to 7 % (Bit128) on MI355X.  The one-workgroup-per-ciphertext
+// kernel, whose wavefronts wait on every dependent step, is 4 % faster with the LDS table
+// (a scalar load's latency is exposed there), so the choice is a template parameter.
 // ---------------------------------------------------------------------------
 // x[n] in re (n = q + 32 r, natural layout) -> spectrum in the S-layout: lane q,
 // register p holds A(q + 32 br5(p)).
+template <bool SCALAR = (WFFT_SCALAR_TWIST != 0)>
 __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[32], double (&im)[32], char* tile,
                                                      const cplx* tE, const cplx* tq, int q) {
-#if WFFT_SCALAR_TWIST
+  if constexpr (SCALAR) {
   // w4096^(q + 32 r) = w4096^q w128^r: the register part comes from the constant segment
   // (scalar loads, no LDS traffic), the lane part is folded into the inter-pass twiddle tE
   (void)tq;
@@ -555,7 +559,7 @@ __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[32], double (&
       re[r] = re[r] * c;
     });
   });
-#else
+  } else {
   wave_lds_fence();
   pipelined_pairs32<WFFT_TWIST_GROUP, cplx>(
       [&](auto ic) WFFT_INLINE { return tq[decltype(ic)::value * 32 + q]; },
@@ -566,17 +570,17 @@ __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[32], double (&
         re[r0] = re[r0] * w0.x;
         re[r1] = re[r1] * w1.x;
       });
-#endif
+  }
   fft1024_fwd(re, im, tile, tE, q);
 }
 
 // Spectrum C in the S-layout -> lo(integral_constant<r>, 1024 c[t]) and, when HI,
 // hi(integral_constant<r>, 1024 c[t + 1024]) for t = q + 32 r.
-template <bool HI, class Lo, class Hi>
+template <bool HI, bool SCALAR = (WFFT_SCALAR_TWIST != 0), class Lo, class Hi>
 __device__ __forceinline__ void inv1024_twisted_real(double (&re)[32], double (&im)[32], char* tile,
                                                      const cplx* tE, const cplx* tq, int q, Lo&& lo,
                                                      Hi&& hi) {
-#if WFFT_SCALAR_TWIST
+  if constexpr (SCALAR) {
   // tq is the inverse's inter-pass table here (conjugated lane part of the twist folded in)
   (void)tE;
   fft1024_inv(re, im, tile, tq, q);
@@ -591,7 +595,7 @@ __device__ __forceinline__ void inv1024_twisted_real(double (&re)[32], double (&
       lo(rc, l);
     });
   });
-#else
+  } else {
   fft1024_inv(re, im, tile, tE, q);
   wave_lds_fence();
   pipelined_pairs32<WFFT_TWIST_GROUP, cplx>(
@@ -610,7 +614,7 @@ __device__ __forceinline__ void inv1024_twisted_real(double (&re)[32], double (&
         lo(i0, l0);
         lo(i1, l1);
       });
-#endif
+  }
 }
 
 // Explicit parking of long-lived values in the accumulation registers (AGPRs).
