@@ -318,7 +318,7 @@ int tfhe_hip_circuit_eq_dev(tfhe_hip_ctx* ctx, const int32_t* a_a, const int32_t
  * The result equals the exact integer convolution (rounded, saturated) as long as
  * an f64 FFT can resolve it: for every operand the path produces (|d| <= Bg/2 <=
  * 2^10 against any Torus32 polynomial) the distance to the nearest rounding
- * boundary stays above 0.19 (tfhe_hip_polymul_margin).  With |d| near 2^15 and
+ * boundary stays above 0.4 (tfhe_hip_polymul_margin).  With |d| near 2^15 and
  * beyond, exact coefficients approach 2^53 and no f64 FFT, the reference's
  * included, determines the integer result any more. */
 int tfhe_hip_polymul(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, int32_t* out,

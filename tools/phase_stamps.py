@@ -45,10 +45,9 @@ if which == "polymul":
     out = torch.empty((B, 2047), dtype=torch.int32, device=dev)
     for _ in range(2):
         eng.polymul_dev(d, s, out)
-    print("polymul2_kernel, per pair of products (32 pairs per wavefront)")
-    show(dict(enumerate(["loop top", "wait for operands", "convert d", "forward d", "park, convert s", "forward s",
-                         "mirror Q", "pointwise", "mirror W2, next fetch", "inverse, twist, swap", "round, store"])),
-         stamps(), 32)
+    print("polymul_kernel, per pair of products (32 pairs per wavefront)")
+    show({0: "loop top", 1: "wait for operands", 2: "convert d", 3: "forward d", 4: "park, convert s, next fetch",
+          5: "forward s", 7: "pointwise", 9: "inverse, untwist", 10: "round, store"}, stamps(), 32)
 else:
     lv = LEVELS[80]
     params = tfhe_amd.make_params(lv["n"], l=lv["l"], bg_bit=lv["bg_bit"])
@@ -69,5 +68,6 @@ else:
               5: "inverse A", 6: "unpark, product B", 7: "inverse B"}, st, 1500)
     else:
         print("blind_rotate_split_kernel (one ciphertext), wavefront 0, per iteration")
-        show(dict(enumerate(["barrier (acc complete)", "rotate", "barrier (tt complete)", "prev, digits", "forward",
-                             "mirror (key loads issued)", "product (key wait)", "inverse, atomics"])), st, 500)
+        show(dict(enumerate(["barrier (acc complete)", "rotate", "barrier (tt complete)",
+                             "prev, digits, first key loads", "forward", "(key prologue when not early)",
+                             "product (key wait)", "inverse, atomics"])), st, 500)
