@@ -39,3 +39,17 @@ def test_level_product_feeds_the_right_result_polynomials():
         w_cross = _exact(d[h], K[h][1 - h])[:1024]
         assert all(int(np.rint(own[h][i])) == w_own[i] for i in range(1024))
         assert all(int(np.rint(cross[h][i])) == w_cross[i] for i in range(1024))
+
+
+def test_scalar_form_of_the_twist_equals_the_table_form():
+    rng = np.random.default_rng(8)
+    d = rng.integers(-512, 512, 1024)
+    s = rng.integers(-2**31, 2**31, 1024)
+    D, S = wm.forward_twisted(d), wm.forward_twisted(s)
+    assert np.allclose(wm.forward_twisted_scalar(d), D, rtol=0, atol=1e-6)
+    assert np.allclose(wm.forward_twisted_scalar(s), S, rtol=0, atol=1e-6 * 2.0**21)
+    lo, hi = wm.inverse_twisted_scalar(wm.forward_twisted_scalar(d) * wm.forward_twisted_scalar(s) / 1024.0)
+    want = _exact(d, s)
+    assert np.max(np.abs(lo - np.rint(lo))) < 0.05 and np.max(np.abs(hi - np.rint(hi))) < 0.05
+    assert all(int(np.rint(lo[i])) == want[i] for i in range(1024))
+    assert all(int(np.rint(hi[i])) == want[1024 + i] for i in range(1023))

@@ -23,12 +23,21 @@ _q = np.arange(Q)
 _r = np.arange(Q)
 T_E = np.exp(-2j * np.pi * np.outer(_q, _r) / 1024)                         # [q][kb] = w1024^(q*kb)
 T_Q = np.exp(-2j * np.pi * (_q[:, None] + 32 * _r[None, :]) / 4096)         # [q][r] = w4096^(q+32r)
+# Scalar form of the twist: w4096^(q+32r) = w4096^q w128^r.  The register part is 32 factors
+# common to all lanes; the lane part is folded into the inter-pass twiddles, one table per
+# direction (the lane index of the input is q before the forward's transpose and n1 after the
+# inverse's).
+W128 = np.exp(-2j * np.pi * _r / 128)                                       # [r]
+T_F = T_E * np.exp(-2j * np.pi * _q / 4096)[:, None]                        # [q][kb] = w1024^(q kb) w4096^q
+T_I = T_E * np.exp(-2j * np.pi * _r / 4096)[None, :]                        # [kb][n1] = w1024^(n1 kb) w4096^n1
 
 
-def fft1024_half(x, inverse=False):
-    """x: [32 lanes][32 regs] complex, element q+32r at [q][r].  Same layout out."""
+def fft1024_half(x, inverse=False, table=None):
+    """x: [32 lanes][32 regs] complex, element q+32r at [q][r].  Same layout out.
+    table: inter-pass twiddles, [lane][reg] at the point of use (default w1024^(q kb))."""
     dft32 = (lambda a: np.fft.ifft(a, axis=1) * 32.0) if inverse else (lambda a: np.fft.fft(a, axis=1))
-    te = T_E.conj() if inverse else T_E
+    te = (T_E if table is None else table)
+    te = te.conj() if inverse else te
     y = dft32(x)                # step A: per lane DFT over registers -> [q][kb]
     y = y * te                  # inter-pass twiddle
     y = y.T.copy()              # transpose: lane kb, reg n1=q
@@ -53,6 +62,17 @@ def forward_twisted(a):
 def inverse_twisted(C):
     """Spectrum of a real polynomial c of degree < 2048 -> (c[0:1024], c[1024:2048]) * 1024."""
     y = fft1024_half(C, inverse=True) * T_Q.conj()
+    return to_poly(y.real), to_poly(-y.imag)
+
+
+def forward_twisted_scalar(a):
+    """forward_twisted with the twist split into w128^r (per register) and the table T_F."""
+    return fft1024_half(to_lanes(np.asarray(a, dtype=np.float64)) * W128[None, :], table=T_F)
+
+
+def inverse_twisted_scalar(C):
+    """inverse_twisted with the lane part of the untwist in the table T_I, w128^r afterwards."""
+    y = fft1024_half(C, inverse=True, table=T_I) * W128.conj()[None, :]
     return to_poly(y.real), to_poly(-y.imag)
 
 
