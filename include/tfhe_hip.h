@@ -94,8 +94,8 @@ int tfhe_hip_synchronize(tfhe_hip_ctx* ctx);
 /* How tfhe_blind_rotate (src/bootstrapping.rs:109-134) is mapped to the GPU.
  * BATCH: one ciphertext per wavefront, persistent workgroups (throughput form).
  * SPLIT: one ciphertext per workgroup, one wavefront per (decomposition level,
- *        key column) pair of tgsw_extern_mul_to_tlwe (src/tgsw.rs:229-264); a
- *        third of the latency, 4/3 of the arithmetic.
+ *        result polynomial) pair of tgsw_extern_mul_to_tlwe (src/tgsw.rs:229-264);
+ *        a third of the latency, 4/3 of the arithmetic.
  * AUTO (default): SPLIT while the batch has at most two ciphertexts per
  *        compute unit, BATCH above.  Results are identical in every mode. */
 enum { TFHE_HIP_BR_AUTO = 0, TFHE_HIP_BR_BATCH = 1, TFHE_HIP_BR_SPLIT = 2 };

@@ -55,7 +55,7 @@ struct StampCtx {
 #endif
 
 // Depth (in groups of four 16-byte loads) of the software pipelines that fetch
-// the two key columns of a level; tuned on MI355X.
+// the two key blocks of a level; tuned on MI355X.
 #ifndef TFHE_K0_DEPTH
 #define TFHE_K0_DEPTH 3
 #endif
@@ -69,7 +69,7 @@ struct StampCtx {
 #endif
 
 
-// Low-latency kernel: the first loads of a wavefront's key column are issued before the
+// Low-latency kernel: the first loads of a wavefront's key block are issued before the
 // forward transform (1) or after it (0); depth of their software pipeline in groups of four.
 #ifndef TFHE_SPLIT_EARLY_KEY
 #define TFHE_SPLIT_EARLY_KEY 1
@@ -524,18 +524,17 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
 
 // ---------------------------------------------------------------------------
 // Small batches: one WORKGROUP per ciphertext.  The (digit polynomial, key
-// column) pairs of an external product are independent until their rounded
-// results meet in the accumulator.  With CPW = 1 (columns per wavefront)
-// wavefront w = 2 p + j takes level p and key column j: digits of level p,
-// forward transform, the real spectrum D_j, product with key_{p,j}, inverse
-// transform; an iteration then costs one forward and one inverse transform per
-// wavefront instead of l and 2 l, at the price of computing each forward
-// transform twice.  With CPW = 2 wavefront w takes level w with both columns
-// (level_product).  Either way the rounded products are added (wrapping, in
-// LDS) into the shared accumulator.  This is the low-latency form, used when
-// the batch cannot fill the machine with one ciphertext per wavefront; l = 3
-// uses CPW = 2 because six wavefronts would have to share four SIMDs and half
-// the registers.
+// polynomial) products of an external product are independent until their rounded
+// results meet in the accumulator.  With CPW = 1 wavefront w = 2 p + u takes level
+// p and result polynomial u: its half-wave h decomposes accumulator polynomial h,
+// transforms the digits, multiplies by K_{h,u} and transforms back; an iteration
+// then costs one forward and one inverse transform per wavefront instead of l and
+// 2 l, at the price of computing each forward transform twice.  With CPW = 2
+// wavefront w takes level w with both result polynomials (level_product).  Either
+// way the rounded products are added (wrapping, in LDS) into the shared
+// accumulator.  This is the low-latency form, used when the batch cannot fill the
+// machine with one ciphertext per wavefront; l = 3 uses CPW = 2 because six
+// wavefronts would have to share four SIMDs and half the registers.
 //
 // LDS: per wavefront the FFT exchange area, then per workgroup prev [2][N],
 // acc [2][N], tt [N][2] (int32), then the twiddle tables.
