@@ -156,14 +156,15 @@ def test_keyswitch(eng, n, n_ks):
         assert var[i] == wv, i
 
 
-@pytest.mark.parametrize("n", [20, 630])
-def test_keyswitch_large_batch(n):
+@pytest.mark.parametrize("n,ks_t", [(20, 8), (630, 8), (33, 5), (16, 11)])
+def test_keyswitch_large_batch(n, ks_t):
     """Batches of at least 8 ciphertexts per compute unit take the tiled key switch (one
-    pass over the key for 8 ciphertexts); a ragged batch must equal the per-ciphertext
-    kernel (same inputs in small chunks) and the oracle."""
+    pass over the key for 8 ciphertexts), for the crate's t = 8 and for other t; a ragged
+    batch must equal the per-ciphertext kernel (same inputs in small chunks) and the oracle."""
     import tfhe_amd
     P = orc.small_params(n=n)
     P.l, P.bg_bit = 2, 10
+    P.ks_t = ks_t
     K = orc.generate_synthetic_keys(P, 140 + n)
     B = 2051
     a = orc.uniform_i32(141, (B, 1024))

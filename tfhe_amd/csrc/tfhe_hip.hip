@@ -1041,13 +1041,14 @@ __global__ __launch_bounds__(kKsBlock) void keyswitch_kernel(
 // branch.  Thread layout and the order of the variance sum as in keyswitch_kernel.
 constexpr int kKsTile = 8;
 
-template <int T>
+template <int TC>   // TC = ks_t when known at compile time, 0 = run-time t_rt
 __global__ __launch_bounds__(kKsBlock) void keyswitch_tile_kernel(
     const int32_t* __restrict__ in_a, const int32_t* __restrict__ in_b,
     const int32_t* __restrict__ in2_a, const int32_t* __restrict__ in2_b, int32_t c_b,
     int in_stride, const int32_t* __restrict__ ks_rows, const double* __restrict__ ks_var,
-    int row_stride, int n, int n_ks, int B, int32_t* __restrict__ out_a,
+    int row_stride, int n, int n_ks, int t_rt, int B, int32_t* __restrict__ out_a,
     int32_t* __restrict__ out_b, double* __restrict__ var_out) {
+  const int T = TC ? TC : t_rt;
   __shared__ int32_t aibar_s[kKsTile][kN];
   __shared__ int4 part[kKsBlock];
   const int b0 = blockIdx.x * kKsTile;
@@ -1577,12 +1578,17 @@ int launch_keyswitch(tfhe_hip_ctx* ctx, const int32_t* in_a, const int32_t* in_b
                      double* var_out, size_t B) {
   const double* ks_var = (const double*)(ctx->ksblob + ctx->ks_rows_bytes);
   ProfileScope prof(ctx, 2);
-  if (ctx->P.ks_t == 8 && B >= (size_t)ctx->num_cus * kKsTile) {
+  if (B >= (size_t)ctx->num_cus * kKsTile) {
     // enough ciphertexts to give every compute unit a tile: share the key reads
     const unsigned grid = (unsigned)((B + kKsTile - 1) / kKsTile);
-    hipLaunchKernelGGL(keyswitch_tile_kernel<8>, dim3(grid), dim3(kKsBlock), 0, ctx->stream, in_a, in_b, in2_a,
-                       in2_b, c_b, kN, (const int32_t*)ctx->ksblob, ks_var, ctx->row_stride, ctx->P.n,
-                       ctx->P.n_ks, (int)B, out_a, out_b, var_out);
+    if (ctx->P.ks_t == 8)
+      hipLaunchKernelGGL(keyswitch_tile_kernel<8>, dim3(grid), dim3(kKsBlock), 0, ctx->stream, in_a, in_b, in2_a,
+                         in2_b, c_b, kN, (const int32_t*)ctx->ksblob, ks_var, ctx->row_stride, ctx->P.n,
+                         ctx->P.n_ks, 8, (int)B, out_a, out_b, var_out);
+    else
+      hipLaunchKernelGGL(keyswitch_tile_kernel<0>, dim3(grid), dim3(kKsBlock), 0, ctx->stream, in_a, in_b, in2_a,
+                         in2_b, c_b, kN, (const int32_t*)ctx->ksblob, ks_var, ctx->row_stride, ctx->P.n,
+                         ctx->P.n_ks, ctx->P.ks_t, (int)B, out_a, out_b, var_out);
   } else if (ctx->P.ks_t == 8)
     hipLaunchKernelGGL(keyswitch_kernel<8>, dim3((unsigned)B), dim3(kKsBlock), 0, ctx->stream, in_a, in_b,
                        in2_a, in2_b, c_b, kN, (const int32_t*)ctx->ksblob, ks_var, ctx->row_stride,
