@@ -60,8 +60,9 @@ for sub, o in (("prof", "bench_kernel_stats"), ("prof_polymul", "polymul_kernel_
             print(row["Name"][:60], row["Calls"], row["AverageNs"], row["Percentage"])
     shutil.copy(ks, f"{P}/{PRE}_{o}.csv")
 shutil.copy(R + "/bench_prof.log", f"{P}/{PRE}_bench_under_rocprof.log")
-if os.path.exists(R + "/valu_cost_ubench.txt"):
-    shutil.copy(R + "/valu_cost_ubench.txt", f"{P}/{PRE}_valu_cost_ubench.txt")
+for name in ("valu_cost_ubench.txt", "lds_cost_ubench.txt"):
+    if os.path.exists(R + "/" + name):
+        shutil.copy(R + "/" + name, f"{P}/{PRE}_{name}")
 sums = json.load(open(R + "/pmc_sums.json"))
 json.dump({"commands": "see tools/measure.sh: one rocprofv3 --pmc run per counter group over "
                        "`bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-latency --no-bit128` "

@@ -24,8 +24,9 @@ timeout -s KILL 200 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST
 PM="python3 bench.py --workload polymul --steps 1 --warmup 0"
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $P/pmc_fetch_polymul -o vm --output-format csv -- $PM > $P/pmc_fetch_polymul.log 2>&1 || exit 1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $P/pmc_write_polymul -o vm --output-format csv -- $PM > $P/pmc_write_polymul.log 2>&1 || exit 1
-# cost of one vector instruction at one wavefront per SIMD
+# cost of one vector / LDS instruction at one and more wavefronts per SIMD
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o /tmp/valu_cost_ubench tools/valu_cost_ubench.hip 2> /dev/null && $T 60 /tmp/valu_cost_ubench > $P/valu_cost_ubench.txt || exit 1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o /tmp/lds_cost_ubench tools/lds_cost_ubench.hip 2> /dev/null && $T 60 /tmp/lds_cost_ubench > $P/lds_cost_ubench.txt || exit 1
 # the CSVs of the counter passes are large; keep per-kernel sums only
 python3 tools/collect_profiles.py $P --sums-only
 rm -rf $P/pmc_*/vm

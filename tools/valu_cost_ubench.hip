@@ -4,6 +4,10 @@
 // Measured on MI355X: 1.88-2.12 ns (one compute unit busy) and 1.90-2.27 ns (all busy) per
 // instruction whatever its type (v_mov_b32 1.96, v_add_f32 1.88, v_add_f64 2.07, v_fma_f64 2.12,
 // v_accvgpr_write_b32 2.25); four clocks of 2.4 GHz would be 1.67 ns.
+// Second part: a transform-like mix (12 v_fma_f64, 2 ds_read_b128, 2 ds_write_b64) at one, two and
+// four wavefronts per SIMD.  Measured: 94.6 ns per group with one wavefront per SIMD (the 12 FMAs
+// alone: 34.2), 47.9 ns per group and SIMD with two, 46.7 with four: a lone wavefront's LDS
+// instructions do not overlap with its own arithmetic, a second wavefront's do.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 template <int OP>
@@ -37,6 +41,59 @@ __global__ __launch_bounds__(1024) void k(unsigned long long* out, double seed, 
   double s = 0; for (int i = 0; i < 16; i++) s += x[i] + f[i] + a[i];
   if (s == 12345.678) out[1] = 1;
 }
+// LDS instructions and a transform-like mix (12 v_fma_f64, 2 ds_read_b128, 2 ds_write_b64 per 16),
+// to see whether a second wavefront on the SIMD overlaps one's LDS transfers with the other's
+// arithmetic.  OP 0: ds_read_b128, 1: ds_write_b64, 2: the mix, 3: the mix's 12 FMAs alone.
+typedef float f4 __attribute__((ext_vector_type(4)));
+template <int OP>
+__global__ __launch_bounds__(1024) void kl(unsigned long long* out, double seed, int iters) {
+  __shared__ __attribute__((aligned(16))) char lds[1024 * 16 * 2];
+  double x[12]; f4 r[2]; double st = seed;
+  for (int i = 0; i < 12; i++) x[i] = seed + i + threadIdx.x;
+  r[0] = r[1] = f4{0, 0, 0, 0};
+  const unsigned addr = threadIdx.x * 16;
+  *reinterpret_cast<f4*>(lds + addr) = r[0];
+  *reinterpret_cast<f4*>(lds + 16384 + addr) = r[0];
+  __syncthreads();
+  double w = 1.0000001, z = 0.5;
+  for (int it = 0; it < iters; it++) {
+#pragma unroll
+    for (int rep = 0; rep < 4; rep++) {
+      if (OP == 0) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) asm volatile("ds_read_b128 %0, %1" : "=v"(r[c & 1]) : "v"(addr + (c & 1) * 16384));
+      } else if (OP == 1) {
+#pragma unroll
+        for (int c = 0; c < 16; c++) asm volatile("ds_write_b64 %0, %1" : : "v"(addr + (c & 1) * 16384), "v"(st));
+      } else {
+#pragma unroll
+        for (int c = 0; c < 12; c++) {
+          asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(x[c]) : "v"(w), "v"(z));
+          if (OP == 2 && (c == 2 || c == 8)) asm volatile("ds_read_b128 %0, %1" : "=v"(r[c == 2]) : "v"(addr + (c == 2) * 16384));
+          if (OP == 2 && (c == 5 || c == 11)) asm volatile("ds_write_b64 %0, %1" : : "v"(addr + (c == 5) * 16384), "v"(st));
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  double s = r[0].x + r[1].y; for (int i = 0; i < 12; i++) s += x[i];
+  if (s == 12345.678) out[1] = 1;
+}
+template <int OP> void run_lds(const char* name, unsigned long long* d, int threads, int per16) {
+  const int iters = 20000, blocks = 256;
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  kl<OP><<<blocks, threads>>>(d, 1.0, iters);
+  hipEventRecord(e0);
+  kl<OP><<<blocks, threads>>>(d, 1.0, iters);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double groups = (double)iters * 4;      // groups of `per16` instructions per wavefront
+  printf("%-44s %d wavefront(s) per SIMD: %7.2f ns per group of a wavefront, %6.2f ns per group and SIMD\n", name,
+         threads / 256, ms * 1e6 / groups, ms * 1e6 / groups / (threads / 256));
+  (void)per16;
+}
+
 template <int OP> void run(const char* name, unsigned long long* d, int blocks, int threads = 256) {
   unsigned long long h[3];
   const int iters = 20000;
@@ -73,6 +130,12 @@ int main() {
     run<1>("v_fma_f64 v,v,v,v", d, 256, threads);
     run<0>("v_add_f64 v,v,v", d, 256, threads);
     run<3>("v_fma_f32", d, 256, threads);
+  }
+  for (int threads : {256, 512, 1024}) {
+    run_lds<0>("16 ds_read_b128", d, threads, 16);
+    run_lds<1>("16 ds_write_b64", d, threads, 16);
+    run_lds<3>("12 v_fma_f64", d, threads, 12);
+    run_lds<2>("12 v_fma_f64 + 2 ds_read_b128 + 2 ds_write_b64", d, threads, 16);
   }
   return 0;
 }
