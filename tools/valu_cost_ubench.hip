@@ -6,8 +6,8 @@
 // v_accvgpr_write_b32 2.25); four clocks of 2.4 GHz would be 1.67 ns.
 // Second part: a transform-like mix (12 v_fma_f64, 2 ds_read_b128, 2 ds_write_b64) at one, two and
 // four wavefronts per SIMD.  Measured: 94.6 ns per group with one wavefront per SIMD (the 12 FMAs
-// alone: 34.2), 47.9 ns per group and SIMD with two, 46.7 with four: a lone wavefront's LDS
-// instructions do not overlap with its own arithmetic, a second wavefront's do.
+// alone: 34.2), 47.9 ns per group and SIMD with two, 46.7 with four: a lone wavefront sits out the
+// LDS round trip at the wait that ends each group, a second wavefront fills it.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 template <int OP>
