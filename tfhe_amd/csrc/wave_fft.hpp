@@ -62,8 +62,8 @@
 // Default of the twisted transforms' SCALAR parameter.  1: the register part of the twist
 // w4096^n (n = q + 32 r -> w128^r) is read with scalar loads from the constant segment and the
 // lane part w4096^q is folded into the inter-pass twiddle tables; 0: the whole twist comes from
-// a table in LDS.  WFFT_SCALAR_GROUP registers share one
-// scalar load (4 -> s_load_dwordx16; 2 and 8 measured slower, 8 through scalar register spills).
+// a table in LDS.  WFFT_SCALAR_GROUP registers share one scalar load (4 -> s_load_dwordx16; 2 and
+// 8 measured slower, 8 through scalar register spills).
 #ifndef WFFT_SCALAR_TWIST
 #define WFFT_SCALAR_TWIST 1
 #endif
@@ -77,12 +77,13 @@ __constant__ double g_w128[64];
 #define WFFT_SCALAR_GROUP 4
 #endif
 
-// The same address in a scalar register the optimiser cannot see through, so that the loads
-// from it stay where they are written instead of being hoisted out of the enclosing loop
-// (all 64 values live at once do not fit the scalar register file).
+// The address of g_w128 (constant address space, so that loads from it are scalar loads) in a
+// scalar register the optimiser cannot see through: the loads then stay where they are written
+// instead of being hoisted out of the enclosing loop (all 64 values live at once do not fit the
+// scalar register file).
 typedef const double __attribute__((address_space(4))) * const_seg_ptr;
-__device__ __forceinline__ const_seg_ptr opaque_const(const double* table) {
-  const_seg_ptr p = (const_seg_ptr)table;
+__device__ __forceinline__ const_seg_ptr w128_ptr() {
+  const_seg_ptr p = (const_seg_ptr)g_w128;
   asm volatile("" : "+s"(p));
   return p;
 }
@@ -547,29 +548,29 @@ template <bool SCALAR = (WFFT_SCALAR_TWIST != 0)>
 __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[32], double (&im)[32], char* tile,
                                                      const cplx* tE, const cplx* tq, int q) {
   if constexpr (SCALAR) {
-  // w4096^(q + 32 r) = w4096^q w128^r: the register part comes from the constant segment
-  // (scalar loads, no LDS traffic), the lane part is folded into the inter-pass twiddle tE
-  (void)tq;
-  static_for<0, 32 / WFFT_SCALAR_GROUP>([&](auto gc) WFFT_INLINE {
-    const_seg_ptr g = opaque_const(g_w128);
-    static_for<0, WFFT_SCALAR_GROUP>([&](auto ic) WFFT_INLINE {
-      constexpr int r = decltype(gc)::value * WFFT_SCALAR_GROUP + decltype(ic)::value;
-      const double c = g[2 * r], s = g[2 * r + 1];
-      im[r] = re[r] * s;
-      re[r] = re[r] * c;
-    });
-  });
-  } else {
-  wave_lds_fence();
-  pipelined_pairs32<WFFT_TWIST_GROUP, cplx>(
-      [&](auto ic) WFFT_INLINE { return tq[decltype(ic)::value * 32 + q]; },
-      [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
-        constexpr int r0 = decltype(i0)::value, r1 = decltype(i1)::value;
-        im[r0] = re[r0] * w0.y;
-        im[r1] = re[r1] * w1.y;
-        re[r0] = re[r0] * w0.x;
-        re[r1] = re[r1] * w1.x;
+    // w4096^(q + 32 r) = w4096^q w128^r: the register part comes from the constant segment
+    // (scalar loads, no LDS traffic), the lane part is folded into the inter-pass twiddle tE
+    (void)tq;
+    static_for<0, 32 / WFFT_SCALAR_GROUP>([&](auto gc) WFFT_INLINE {
+      const_seg_ptr g = w128_ptr();
+      static_for<0, WFFT_SCALAR_GROUP>([&](auto ic) WFFT_INLINE {
+        constexpr int r = decltype(gc)::value * WFFT_SCALAR_GROUP + decltype(ic)::value;
+        const double c = g[2 * r], s = g[2 * r + 1];
+        im[r] = re[r] * s;
+        re[r] = re[r] * c;
       });
+    });
+  } else {
+    wave_lds_fence();
+    pipelined_pairs32<WFFT_TWIST_GROUP, cplx>(
+        [&](auto ic) WFFT_INLINE { return tq[decltype(ic)::value * 32 + q]; },
+        [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
+          constexpr int r0 = decltype(i0)::value, r1 = decltype(i1)::value;
+          im[r0] = re[r0] * w0.y;
+          im[r1] = re[r1] * w1.y;
+          re[r0] = re[r0] * w0.x;
+          re[r1] = re[r1] * w1.x;
+        });
   }
   fft1024_fwd(re, im, tile, tE, q);
 }
@@ -581,39 +582,39 @@ __device__ __forceinline__ void inv1024_twisted_real(double (&re)[32], double (&
                                                      const cplx* tE, const cplx* tq, int q, Lo&& lo,
                                                      Hi&& hi) {
   if constexpr (SCALAR) {
-  // tq is the inverse's inter-pass table here (conjugated lane part of the twist folded in)
-  (void)tE;
-  fft1024_inv(re, im, tile, tq, q);
-  static_for<0, 32 / WFFT_SCALAR_GROUP>([&](auto gc) WFFT_INLINE {
-    const_seg_ptr g = opaque_const(g_w128);
-    static_for<0, WFFT_SCALAR_GROUP>([&](auto ic) WFFT_INLINE {
-      constexpr int r = decltype(gc)::value * WFFT_SCALAR_GROUP + decltype(ic)::value;
-      const std::integral_constant<int, r> rc;
-      const double c = g[2 * r], s = g[2 * r + 1];
-      const double l = re[r] * c + im[r] * s;          // y conj(w128^r)
-      if constexpr (HI) hi(rc, re[r] * s - im[r] * c);
-      lo(rc, l);
-    });
-  });
-  } else {
-  fft1024_inv(re, im, tile, tE, q);
-  wave_lds_fence();
-  pipelined_pairs32<WFFT_TWIST_GROUP, cplx>(
-      [&](auto ic) WFFT_INLINE { return tq[decltype(ic)::value * 32 + q]; },
-      [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
-        constexpr int r0 = decltype(i0)::value, r1 = decltype(i1)::value;
-        // y conj(w) = (yr c + yi s) + i (yi c - yr s)
-        const double l0 = re[r0] * w0.x + im[r0] * w0.y;
-        const double l1 = re[r1] * w1.x + im[r1] * w1.y;
-        if constexpr (HI) {
-          const double h0 = re[r0] * w0.y - im[r0] * w0.x;
-          const double h1 = re[r1] * w1.y - im[r1] * w1.x;
-          hi(i0, h0);
-          hi(i1, h1);
-        }
-        lo(i0, l0);
-        lo(i1, l1);
+    // tq is the inverse's inter-pass table here (conjugated lane part of the twist folded in)
+    (void)tE;
+    fft1024_inv(re, im, tile, tq, q);
+    static_for<0, 32 / WFFT_SCALAR_GROUP>([&](auto gc) WFFT_INLINE {
+      const_seg_ptr g = w128_ptr();
+      static_for<0, WFFT_SCALAR_GROUP>([&](auto ic) WFFT_INLINE {
+        constexpr int r = decltype(gc)::value * WFFT_SCALAR_GROUP + decltype(ic)::value;
+        const std::integral_constant<int, r> rc;
+        const double c = g[2 * r], s = g[2 * r + 1];
+        const double l = re[r] * c + im[r] * s;          // y conj(w128^r)
+        if constexpr (HI) hi(rc, re[r] * s - im[r] * c);
+        lo(rc, l);
       });
+    });
+  } else {
+    fft1024_inv(re, im, tile, tE, q);
+    wave_lds_fence();
+    pipelined_pairs32<WFFT_TWIST_GROUP, cplx>(
+        [&](auto ic) WFFT_INLINE { return tq[decltype(ic)::value * 32 + q]; },
+        [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
+          constexpr int r0 = decltype(i0)::value, r1 = decltype(i1)::value;
+          // y conj(w) = (yr c + yi s) + i (yi c - yr s)
+          const double l0 = re[r0] * w0.x + im[r0] * w0.y;
+          const double l1 = re[r1] * w1.x + im[r1] * w1.y;
+          if constexpr (HI) {
+            const double h0 = re[r0] * w0.y - im[r0] * w0.x;
+            const double h1 = re[r1] * w1.y - im[r1] * w1.x;
+            hi(i0, h0);
+            hi(i1, h1);
+          }
+          lo(i0, l0);
+          lo(i1, l1);
+        });
   }
 }
 
