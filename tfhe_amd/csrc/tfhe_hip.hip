@@ -304,7 +304,8 @@ struct RegisterSink {
     wfft::wave_lds_fence();
     static_for<0, 8>([&](auto gc) WFFT_INLINE {
       constexpr int g = decltype(gc)::value;
-      *reinterpret_cast<int4v*>(mine + g * 1024) = int4v{x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+      *reinterpret_cast<int4v*>(mine + g * 1024) =
+          int4v{x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
     });
     wfft::wave_lds_fence();
     static_for<0, 8>([&](auto gc) WFFT_INLINE {
@@ -617,8 +618,8 @@ __global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel
     }
     const char* tt = reinterpret_cast<const char*>(ttL) + q * 8;
     if constexpr (CPW == 2) {
-      level_product<BGBIT, kSplitScalar>(p, tt, args.bkfft + ((size_t)i * L + p) * 2 * 2048, wave_tiles, tE, tq, lane,
-                           accumulate, st);
+      level_product<BGBIT, kSplitScalar>(p, tt, args.bkfft + ((size_t)i * L + p) * 2 * 2048, wave_tiles, tE, tq,
+                                         lane, accumulate, st);
     } else {
     // this wavefront's level p and result polynomial u: half-wave h takes digit polynomial
     // h, so both halves contribute (each rounded on its own) to the same result polynomial
