@@ -69,8 +69,8 @@ int tfhe_hip_create(tfhe_hip_ctx** out, int device);
  *   - tfhe_hip_load_keys / tfhe_hip_load_keys_blob transform the keys on
  *     devices[0] and replicate the device blobs once: an RCCL broadcast
  *     (ncclCommInitAll + ncclBroadcast over xGMI) between distinct GPUs,
- *     peer-to-peer copies if RCCL is unavailable, a device-to-device copy
- *     between workers that share a GPU;
+ *     peer-to-peer copies if RCCL is unavailable or fails, a device-to-device
+ *     copy between workers that share a GPU (tfhe_hip_key_transport says which);
  *   - every host-pointer entry point and every tfhe_hip_samples_* call splits its
  *     batch contiguously over the workers (tfhe_hip_circuit_add by instance, so
  *     that all dependency levels of an instance stay on one GPU), runs the
@@ -81,6 +81,14 @@ int tfhe_hip_create(tfhe_hip_ctx** out, int device);
  *     need a single-device context and fail with TFHE_HIP_ERR_ARG here.
  * Results are bit-identical to those of a single-device context. */
 int tfhe_hip_create_multi(tfhe_hip_ctx** out, const int* devices, int ndev);
+/* How the loaded keys reached the other GPUs of a multi-GPU context: "rccl" (one
+ * broadcast), "peer" (hipMemcpyPeerAsync from devices[0], peer access enabled where the
+ * hardware offers it), "local" (all workers share one GPU: device-to-device copies), "none"
+ * (single-device context, or no keys loaded).  No counterpart in the reference. */
+const char* tfhe_hip_key_transport(tfhe_hip_ctx* ctx);
+/* Releases the context and everything it owns on its GPU(s), including the device memory of
+ * sample handles that are still alive: such a handle stays valid only as an argument of
+ * tfhe_hip_samples_free. */
 void tfhe_hip_destroy(tfhe_hip_ctx* ctx);
 const char* tfhe_hip_last_error(tfhe_hip_ctx* ctx);
 
@@ -136,8 +144,13 @@ int tfhe_hip_load_keys(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, const i
  * The reference draws from rand's thread_rng (an OS-seeded ChaCha generator that
  * callers cannot seed); here every random value is a documented function of
  * `seed` (32 bytes = the ChaCha20 key, RFC 8439 block function; the addressing
- * is described at the kernels), so a seed reproduces its keys.  Use a seed from
- * the operating system's entropy source for real keys.
+ * is described at the kernels), so a seed reproduces its keys.
+ * NOT SECURE KEY MATERIAL: as in the reference, the gadget term lands on an unencrypted
+ * coefficient (the body polynomial of a row-0 sample is [key bit * l, 0 .. 0, noise]), so
+ * bk_out and the device-side cloud key expose every LWE secret key bit in the clear.  The
+ * output reproduces the reference's key structure for parity tests and benchmarks; it must
+ * not protect real data.  The device copies of the secret keys and noises are zeroed
+ * before the call returns.
  * On return the context holds the keys exactly as after tfhe_hip_load_keys (on a
  * multi-GPU context: generated on devices[0], then replicated) and the SECRET
  * keys are in lwe_key [n] and tlwe_key [(k+1)][N] (may be NULL).  bk_out, ks_a_out,

@@ -57,6 +57,7 @@ extern "C" {
         devices: *const c_int,
         ndev: c_int,
     ) -> c_int;
+    pub fn tfhe_hip_key_transport(ctx: *mut TfheHipCtx) -> *const c_char;
     pub fn tfhe_hip_destroy(ctx: *mut TfheHipCtx);
     pub fn tfhe_hip_last_error(ctx: *mut TfheHipCtx) -> *const c_char;
     pub fn tfhe_hip_set_stream(ctx: *mut TfheHipCtx, hip_stream: *mut c_void) -> c_int;

@@ -13,30 +13,36 @@
 //!   * fields this module reads become `pub(crate)`: `LweKeySwitchKey::{n, t, base_bit, ks}`
 //!     (src/lwe.rs:496-513), `TGswSample::all_sample` (src/tgsw.rs:99),
 //!     `TGswParams::{l, bg_bit}` (src/tgsw.rs:10-13), `LweParams::n`
-//!   * `CloudKey` gains `pub(crate) gpu: std::sync::Arc<gpu::GpuKeys>` built in
-//!     `CloudKey::new` (src/lwe.rs:253-257) with `#[serde(skip)]` and rebuilt after
-//!     deserialisation
-//!   * with `--features bootstrapping`, the gate bodies of src/gates.rs call
-//!     `gpu::gate(..)` (table at the end of this file) and `tfhe_bootstrap`
-//!     (src/bootstrapping.rs:25-29) calls `gpu::bootstrap(..)`.
+//!   * `LweBootstrappingKey` (src/lwe.rs:432-446) gains `#[serde(skip)] pub(crate) gpu: gpu::GpuSlot`
+//!     (`GpuSlot::default()` in `LweBootstrappingKey::new`, src/lwe.rs:464-471).  The slot is
+//!     empty until the first bootstrapped call, which flattens the key and uploads it; it is
+//!     `Clone` (clones share the uploaded keys) and comes back empty from deserialisation.
+//!     The handle sits on the bootstrapping key, not on `CloudKey`, because
+//!     `tfhe_bootstrap(bk: &LweBootstrappingKey, ..)` (src/bootstrapping.rs:25) only sees that:
+//!     its callers pass `&cloud_key.bk` (src/gates.rs:35, benches/bootstrapping.rs:21).
+//!   * with `--features bootstrapping`, `tfhe_bootstrap` (src/bootstrapping.rs:25-29) calls
+//!     `gpu::bootstrap(&bk.gpu.get(bk), mu, x)` and the gate bodies of src/gates.rs, which
+//!     take `bk: &CloudKey`, call `gpu::gate(&bk.bk.gpu.get(&bk.bk), ..)` (table at the end
+//!     of this file).
 #![allow(unsafe_code)]
 use crate::ffi::*;
-use crate::lwe::{CloudKey, LweBootstrappingKey, LweSample};
+use crate::lwe::{LweBootstrappingKey, LweSample};
 use crate::numerics::Torus32;
 use std::ffi::CStr;
 use std::os::raw::c_int;
 use std::ptr;
-use std::sync::Mutex;
+use std::sync::{Arc, Mutex};
 
-/// The keys of one `CloudKey`, resident on the GPU(s).  A context is not re-entrant
-/// (one call at a time), hence the mutex; the crate's own API is single-threaded.
+/// The keys of one `LweBootstrappingKey`, resident on the GPU(s).  A context is not
+/// re-entrant (one call at a time): every FFI call below runs with the mutex HELD, the guard
+/// is dropped only after the call and its error check have returned.
 pub struct GpuKeys {
     ctx: Mutex<*mut TfheHipCtx>,
     n: usize,
     big_n: usize,
 }
 
-// The raw context pointer is only used under the mutex.
+// The raw context pointer is only dereferenced (by the library) while the mutex is held.
 unsafe impl Send for GpuKeys {}
 unsafe impl Sync for GpuKeys {}
 
@@ -51,7 +57,9 @@ fn check(ctx: *mut TfheHipCtx, rc: c_int) {
 impl GpuKeys {
     /// `devices`: GPU ordinals; one entry = single-GPU context, several = batches are split
     /// over them and the keys are replicated once (RCCL broadcast inside the library).
-    pub fn new(bk: &LweBootstrappingKey, ks_t: i32, ks_base_bit: i32, devices: &[i32]) -> Self {
+    pub fn new(bk: &LweBootstrappingKey, devices: &[i32]) -> Self {
+        // decomposition length and log2(base) of the key-switch key (src/lwe.rs:498-502)
+        let (ks_t, ks_base_bit) = (bk.ks.t, bk.ks.base_bit);
         let n = bk.in_out_params.n as usize;
         let big_n = bk.accum_params.n as usize;
         let k = bk.accum_params.k as usize;
@@ -121,8 +129,43 @@ impl GpuKeys {
 
 impl Drop for GpuKeys {
     fn drop(&mut self) {
-        let ctx = *self.ctx.lock().unwrap();
-        unsafe { tfhe_hip_destroy(ctx) };
+        // a poisoned mutex still guards a live context: destroy it either way
+        let guard = self.ctx.lock().unwrap_or_else(|e| e.into_inner());
+        unsafe { tfhe_hip_destroy(*guard) };
+        drop(guard);
+    }
+}
+
+/// GPU ordinals a freshly built `GpuKeys` uses: `TFHE_HIP_DEVICES=0,1,2,3` (default `0`).
+fn devices_from_env() -> Vec<i32> {
+    std::env::var("TFHE_HIP_DEVICES")
+        .ok()
+        .map(|v| v.split(',').filter_map(|d| d.trim().parse().ok()).collect::<Vec<i32>>())
+        .filter(|v| !v.is_empty())
+        .unwrap_or_else(|| vec![0])
+}
+
+/// The field `LweBootstrappingKey` gains: the uploaded keys, built on first use.
+#[derive(Default)]
+pub struct GpuSlot(Mutex<Option<Arc<GpuKeys>>>);
+
+impl GpuSlot {
+    /// The uploaded keys of `bk` (the key this slot is a field of); flattens and uploads them
+    /// on the first call.
+    pub fn get(&self, bk: &LweBootstrappingKey) -> Arc<GpuKeys> {
+        let mut slot = self.0.lock().unwrap();
+        slot.get_or_insert_with(|| Arc::new(GpuKeys::new(bk, &devices_from_env()))).clone()
+    }
+    /// As `get`, on an explicit device list (several entries: batches are split over them).
+    pub fn get_on(&self, bk: &LweBootstrappingKey, devices: &[i32]) -> Arc<GpuKeys> {
+        let mut slot = self.0.lock().unwrap();
+        slot.get_or_insert_with(|| Arc::new(GpuKeys::new(bk, devices))).clone()
+    }
+}
+
+impl Clone for GpuSlot {
+    fn clone(&self) -> Self {
+        GpuSlot(Mutex::new(self.0.lock().unwrap().clone()))
     }
 }
 
@@ -154,12 +197,14 @@ pub fn bootstrap_many(keys: &GpuKeys, mu: Torus32, xs: &[&LweSample]) -> Vec<Lwe
     let (n, batch) = (keys.n, xs.len());
     let (a, b) = flatten(xs, n);
     let (mut out_a, mut out_b, mut var) = (vec![0i32; batch * n], vec![0i32; batch], vec![0f64; batch]);
-    let ctx = *keys.ctx.lock().unwrap();
+    let guard = keys.ctx.lock().unwrap();
+    let ctx = *guard;
     let rc = unsafe {
         tfhe_hip_bootstrap(ctx, mu, a.as_ptr(), b.as_ptr(), out_a.as_mut_ptr(), out_b.as_mut_ptr(),
                            var.as_mut_ptr(), batch)
     };
     check(ctx, rc);
+    drop(guard);
     unflatten(out_a, out_b, var, n)
 }
 
@@ -172,11 +217,13 @@ pub fn bootstrap(keys: &GpuKeys, mu: Torus32, x: LweSample) -> LweSample {
 pub fn bootstrap_without_key_switching(keys: &GpuKeys, mu: Torus32, x: LweSample) -> LweSample {
     let (a, b) = flatten(&[&x], keys.n);
     let (mut out_a, mut out_b) = (vec![0i32; keys.big_n], vec![0i32; 1]);
-    let ctx = *keys.ctx.lock().unwrap();
+    let guard = keys.ctx.lock().unwrap();
+    let ctx = *guard;
     let rc = unsafe {
         tfhe_hip_bootstrap_noks(ctx, mu, a.as_ptr(), b.as_ptr(), out_a.as_mut_ptr(), out_b.as_mut_ptr(), 1)
     };
     check(ctx, rc);
+    drop(guard);
     LweSample { coefficients: out_a, b: out_b[0], current_variance: 0.0 }
 }
 
@@ -184,12 +231,14 @@ pub fn bootstrap_without_key_switching(keys: &GpuKeys, mu: Torus32, x: LweSample
 pub fn key_switch(keys: &GpuKeys, x: LweSample) -> LweSample {
     assert_eq!(x.coefficients.len(), keys.big_n);
     let (mut out_a, mut out_b, mut var) = (vec![0i32; keys.n], vec![0i32; 1], vec![0f64; 1]);
-    let ctx = *keys.ctx.lock().unwrap();
+    let guard = keys.ctx.lock().unwrap();
+    let ctx = *guard;
     let rc = unsafe {
         tfhe_hip_keyswitch(ctx, x.coefficients.as_ptr(), &x.b, out_a.as_mut_ptr(), out_b.as_mut_ptr(),
                            var.as_mut_ptr(), 1)
     };
     check(ctx, rc);
+    drop(guard);
     LweSample { coefficients: out_a, b: out_b[0], current_variance: var[0] }
 }
 
@@ -215,12 +264,14 @@ pub fn gate_many(
         None => (ptr::null(), ptr::null()),
     };
     let (mut out_a, mut out_b, mut var) = (vec![0i32; batch * n], vec![0i32; batch], vec![0f64; batch]);
-    let ctx = *keys.ctx.lock().unwrap();
+    let guard = keys.ctx.lock().unwrap();
+    let ctx = *guard;
     let rc = unsafe {
         tfhe_hip_gate(ctx, gate, ca_a.as_ptr(), ca_b.as_ptr(), cb_a.as_ptr(), cb_b.as_ptr(), cc_a, cc_b,
                       out_a.as_mut_ptr(), out_b.as_mut_ptr(), var.as_mut_ptr(), batch)
     };
     check(ctx, rc);
+    drop(guard);
     unflatten(out_a, out_b, var, n)
 }
 
@@ -259,13 +310,15 @@ pub fn add_many(
     let (mut s_a, mut s_b, mut s_v) =
         (vec![0i32; bits * count * n], vec![0i32; bits * count], vec![0f64; bits * count]);
     let (mut c_a, mut c_b, mut c_v) = (vec![0i32; count * n], vec![0i32; count], vec![0f64; count]);
-    let ctx = *keys.ctx.lock().unwrap();
+    let guard = keys.ctx.lock().unwrap();
+    let ctx = *guard;
     let rc = unsafe {
         tfhe_hip_circuit_add(ctx, a_a.as_ptr(), a_b.as_ptr(), b_a.as_ptr(), b_b.as_ptr(), s_a.as_mut_ptr(),
                              s_b.as_mut_ptr(), c_a.as_mut_ptr(), c_b.as_mut_ptr(), s_v.as_mut_ptr(),
                              c_v.as_mut_ptr(), count, bits as c_int)
     };
     check(ctx, rc);
+    drop(guard);
     (0..count)
         .map(|i| {
             let sum = (0..bits)
@@ -290,22 +343,21 @@ pub fn add_many(
 
 // With `--features bootstrapping` the gate bodies of src/gates.rs become one line each:
 //
-//   pub fn nand(ca, cb, bk)  -> gpu::gate(&bk.gpu, ffi::NAND,  ca, cb)     // src/gates.rs:23-41
-//   pub fn or(ca, cb, bk)    -> gpu::gate(&bk.gpu, ffi::OR,    ca, cb)     // :44-61
-//   pub fn and(ca, cb, bk)   -> gpu::gate(&bk.gpu, ffi::AND,   ca, cb)     // :64-80
-//   pub fn xor(ca, cb, bk)   -> gpu::gate(&bk.gpu, ffi::XOR,   ca, cb)     // :83-99
-//   pub fn xnor(ca, cb, bk)  -> gpu::gate(&bk.gpu, ffi::XNOR,  ca, cb)     // :102-119
-//   pub fn nor(ca, cb, bk)   -> gpu::gate(&bk.gpu, ffi::NOR,   ca, cb)     // :127-143
-//   pub fn andny(ca, cb, bk) -> gpu::gate(&bk.gpu, ffi::ANDNY, ca, cb)     // :147-162
-//   pub fn andyn(ca, cb, bk) -> gpu::gate(&bk.gpu, ffi::ANDYN, ca, cb)     // :166-182
-//   pub fn orny(ca, cb, bk)  -> gpu::gate(&bk.gpu, ffi::ORNY,  ca, cb)     // :186-202
-//   pub fn oryn(ca, cb, bk)  -> gpu::gate(&bk.gpu, ffi::ORYN,  ca, cb)     // :206-222
-//   pub fn mux(a, b, c, bk)  -> gpu::mux(&bk.gpu, a, b, c)                 // :239-268
-//   pub fn tfhe_bootstrap(bk, mu, x) -> gpu::bootstrap(&cloud.gpu, mu, x)  // src/bootstrapping.rs:25-29
-//   circuits::add(a, b, key) -> gpu::add_many(&key.gpu, &[a], &[b]).pop()  // src/circuits/circuits.rs:105-120
+//   pub fn nand(ca, cb, bk)  -> gpu::gate(&bk.bk.gpu.get(&bk.bk), ffi::NAND,  ca, cb)     // src/gates.rs:23-41
+//   pub fn or(ca, cb, bk)    -> gpu::gate(&bk.bk.gpu.get(&bk.bk), ffi::OR,    ca, cb)     // :44-61
+//   pub fn and(ca, cb, bk)   -> gpu::gate(&bk.bk.gpu.get(&bk.bk), ffi::AND,   ca, cb)     // :64-80
+//   pub fn xor(ca, cb, bk)   -> gpu::gate(&bk.bk.gpu.get(&bk.bk), ffi::XOR,   ca, cb)     // :83-99
+//   pub fn xnor(ca, cb, bk)  -> gpu::gate(&bk.bk.gpu.get(&bk.bk), ffi::XNOR,  ca, cb)     // :102-119
+//   pub fn nor(ca, cb, bk)   -> gpu::gate(&bk.bk.gpu.get(&bk.bk), ffi::NOR,   ca, cb)     // :127-143
+//   pub fn andny(ca, cb, bk) -> gpu::gate(&bk.bk.gpu.get(&bk.bk), ffi::ANDNY, ca, cb)     // :147-162
+//   pub fn andyn(ca, cb, bk) -> gpu::gate(&bk.bk.gpu.get(&bk.bk), ffi::ANDYN, ca, cb)     // :166-182
+//   pub fn orny(ca, cb, bk)  -> gpu::gate(&bk.bk.gpu.get(&bk.bk), ffi::ORNY,  ca, cb)     // :186-202
+//   pub fn oryn(ca, cb, bk)  -> gpu::gate(&bk.bk.gpu.get(&bk.bk), ffi::ORYN,  ca, cb)     // :206-222
+//   pub fn mux(a, b, c, bk)  -> gpu::mux(&bk.bk.gpu.get(&bk.bk), a, b, c)                // :239-268
+//   pub fn tfhe_bootstrap(bk: &LweBootstrappingKey, mu, x)
+//                            -> gpu::bootstrap(&bk.gpu.get(bk), mu, x)     // src/bootstrapping.rs:25-29
+//   circuits::add(a, b, key) -> gpu::add_many(&key.bk.gpu.get(&key.bk), &[a], &[b]).pop()  // src/circuits/circuits.rs:105-120
 //
 // `not`, `constant`, `encrypt`, `decrypt`, `generate_keys` stay as they are (host).
 // Chained gates that should not cross PCIe use the sample handles
 // (tfhe_hip_samples_alloc / _upload / _gate / _not / _constant / _download in ffi.rs).
-#[allow(dead_code)]
-fn _cloud_key_wiring(_: &CloudKey) {}

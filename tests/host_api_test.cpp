@@ -33,7 +33,7 @@ int main() {
   // key structure the crate's generate_keys produces
   const size_t sample = (size_t)P.l * 4 * P.N;
   for (int i = 0; i < P.n; i++) {
-    const int32_t* s = ck.bk.data() + i * sample;
+    const int32_t* s = ck.bk.bk.data() + i * sample;
     for (size_t x = 2 * 2 * (size_t)P.N; x < sample; x++) CHECK(s[x] == 0, "row >= 1 not zero");
     CHECK(s[1 * P.N] == sk.lwe_key[i] * P.l, "b-poly coefficient 0");
     CHECK(s[3 * P.N] == sk.lwe_key[i] * P.l, "b-poly coefficient 0 (col 1)");
@@ -56,7 +56,7 @@ int main() {
     for (int bits = 0; bits < 4; bits++) {
       const LweSample a = encrypt(bits & 1, sk), b = encrypt(bits & 2, sk);
       const LweSample got = g.fn(a, b, ck);
-      orc_gate(&P, g.orc, ck.bk.data(), nullptr, ck.ks_a.data(), ck.ks_b.data(), ck.ks_var.data(),
+      orc_gate(&P, g.orc, ck.bk.bk.data(), nullptr, ck.bk.ks.a.data(), ck.bk.ks.b.data(), ck.bk.ks.var.data(),
                a.coefficients.data(), a.b, a.current_variance, b.coefficients.data(), b.b,
                b.current_variance, a.coefficients.data(), 0, 0.0, oa.data(), &ob, &ov, ORC_MUL_FFT,
                nullptr);
@@ -66,12 +66,12 @@ int main() {
   {
     const LweSample a = encrypt(true, sk), b = encrypt(false, sk), c = encrypt(true, sk);
     const LweSample got = mux(a, b, c, ck);
-    orc_gate(&P, ORC_GATE_MUX, ck.bk.data(), nullptr, ck.ks_a.data(), ck.ks_b.data(), ck.ks_var.data(),
+    orc_gate(&P, ORC_GATE_MUX, ck.bk.bk.data(), nullptr, ck.bk.ks.a.data(), ck.bk.ks.b.data(), ck.bk.ks.var.data(),
              a.coefficients.data(), a.b, 0.0, b.coefficients.data(), b.b, 0.0, c.coefficients.data(),
              c.b, 0.0, oa.data(), &ob, &ov, ORC_MUL_FFT, nullptr);
     CHECK(got.coefficients == oa && got.b == ob && got.current_variance == ov, "mux differs");
-    const LweSample bs = tfhe_bootstrap(ck, encode_message(1, 8), a);
-    orc_bootstrap(&P, ck.bk.data(), nullptr, ck.ks_a.data(), ck.ks_b.data(), ck.ks_var.data(),
+    const LweSample bs = tfhe_bootstrap(ck.bk, encode_message(1, 8), a);
+    orc_bootstrap(&P, ck.bk.bk.data(), nullptr, ck.bk.ks.a.data(), ck.bk.ks.b.data(), ck.bk.ks.var.data(),
                   encode_message(1, 8), a.coefficients.data(), a.b, oa.data(), &ob, &ov, ORC_MUL_FFT,
                   nullptr);
     CHECK(bs.coefficients == oa && bs.b == ob && bs.current_variance == ov, "tfhe_bootstrap differs");
@@ -133,10 +133,10 @@ int main() {
     for (int i = 0; i < 32; i++) seed[i] = (uint8_t)(7 * i + 3);
     auto [gsk, gck] = generate_keys_gpu(params, seed);
     auto [gsk2, gck2] = generate_keys_gpu(params, seed);
-    CHECK(gsk.lwe_key == gsk2.lwe_key && gck.bk == gck2.bk && gck.ks_a == gck2.ks_a && gck.ks_b == gck2.ks_b,
+    CHECK(gsk.lwe_key == gsk2.lwe_key && gck.bk.bk == gck2.bk.bk && gck.bk.ks.a == gck2.bk.ks.a && gck.bk.ks.b == gck2.bk.ks.b,
           "generate_keys_gpu: a seed does not reproduce its keys");
     for (int i = 0; i < P.n; i++) {
-      const int32_t* s = gck.bk.data() + i * sample;
+      const int32_t* s = gck.bk.bk.data() + i * sample;
       for (size_t x = 2 * 2 * (size_t)P.N; x < sample; x++) CHECK(s[x] == 0, "gpu keys: row >= 1 not zero");
       CHECK(s[1 * P.N] == gsk.lwe_key[i] * P.l, "gpu keys: b-poly coefficient 0");
     }
@@ -149,7 +149,7 @@ int main() {
     for (int bits = 0; bits < 4; bits++) {
       const LweSample &a = va[bits], &b = vb[bits];
       const LweSample got = nand(a, b, gck);
-      orc_gate(&P, ORC_GATE_NAND, gck.bk.data(), nullptr, gck.ks_a.data(), gck.ks_b.data(), gck.ks_var.data(),
+      orc_gate(&P, ORC_GATE_NAND, gck.bk.bk.data(), nullptr, gck.bk.ks.a.data(), gck.bk.ks.b.data(), gck.bk.ks.var.data(),
                a.coefficients.data(), a.b, a.current_variance, b.coefficients.data(), b.b,
                b.current_variance, a.coefficients.data(), 0, 0.0, oa.data(), &ob, &ov, ORC_MUL_FFT, nullptr);
       CHECK(got.coefficients == oa && got.b == ob && got.current_variance == ov, "gpu keys: nand vs oracle %d", bits);

@@ -171,6 +171,11 @@ def test_seed_reproduces_keys_and_key_file_round_trip(generated80):
         r2, r3 = e2.gate("nand", a, b, want_var=True), e3.gate("nand", a, b, want_var=True)
         for x, y in zip(r2, r3):
             assert (x == y).all()
+        # and both equal the oracle on the exported keys (first hand, not only each other)
+        Ko = {k: np.ascontiguousarray(v) for k, v in K.items()}
+        for i in (0, 4):
+            wa, wb, wv = orc.gate(P, "nand", Ko, (a[0][i], a[1][i], 0.0), (b[0][i], b[1][i], 0.0), None, orc.MUL_FFT)
+            assert (r3[0][i] == wa).all() and r3[1][i] == wb and r3[2][i] == wv, i
     finally:
         e2.close()
         e3.close()

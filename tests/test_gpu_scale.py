@@ -335,6 +335,15 @@ def test_sample_handles_chain_equals_host_calls(eng):
     assert not one[0].any() and (one[1] == 1 << 29).all() and not one[2].any()
     x = eng.gate("nand", ca, cb, want_var=True)
     assert (nx[0] == -x[0]).all() and (nx[1] == -x[1]).all() and (nx[2] == x[2]).all()
+    # the handle chain against the oracle composed gate by gate (src/gates.rs:23-41,83-99,122-124,239-268)
+    for i in (0, B - 1):
+        sa, sb, sc = ((c[0][i], c[1][i], 0.0) for c in (ca, cb, cc))
+        ox = orc.gate(P, "nand", K, sa, sb, None, orc.MUL_EXACT)
+        oy = orc.gate(P, "xor", K, ox, sc, None, orc.MUL_EXACT)
+        onx = (-ox[0], (-ox[1] + 2 ** 31) % 2 ** 32 - 2 ** 31, ox[2])      # gates::not, wrapping
+        oz = orc.gate(P, "mux", K, oy, sa, onx, orc.MUL_EXACT)
+        assert (y[0][i] == oy[0]).all() and y[1][i] == oy[1] and y[2][i] == oy[2], i
+        assert (z[0][i] == oz[0]).all() and z[1][i] == oz[1] and z[2][i] == oz[2], i
     # errors: size mismatch, foreign handle
     import tfhe_amd
     h1, h2 = eng.samples(3), eng.samples(4)
@@ -364,6 +373,11 @@ def test_key_file_loads_like_load_keys(eng):
         got = e2.gate("xnor", ca, cb, want_var=True)
         for g, w in zip(got, want):
             assert (g == w).all()
+        # the context that only ever saw the key file against the oracle on the original keys
+        for i in range(B):
+            wa, wb, wv = orc.gate(P, "xnor", K, (ca[0][i], ca[1][i], 0.0), (cb[0][i], cb[1][i], 0.0), None,
+                                  orc.MUL_EXACT)
+            assert (got[0][i] == wa).all() and got[1][i] == wb and got[2][i] == wv, i
         # an unaligned copy of the image loads too
         raw = np.empty(image.size + 1, np.uint8)
         raw[1:] = image
@@ -447,7 +461,7 @@ def test_multi_context_rccl_replication_in_a_fresh_process():
         "P = orc.small_params(n=5); K = orc.generate_synthetic_keys(P, 2400)\n"
         "hp = tfhe_amd.make_params(P.n, n_ks=P.n_ks)\n"
         "m = tfhe_amd.Engine([0, 0]); m.load_keys(hp, K['bk'], K['ks_a'], K['ks_b'], K['ks_var'])\n"
-        "print('MSG', m.last_message())\n"
+        "print('MSG transport', m.key_transport())\n"
         "ca = (orc.uniform_i32(1, (3, P.n)), orc.uniform_i32(2, (3,)))\n"
         "oa, ob = m.gate('nand', ca, ca)\n"
         "for i in range(3):\n"
@@ -456,7 +470,35 @@ def test_multi_context_rccl_replication_in_a_fresh_process():
         "m.close(); print('DONE')\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
     assert r.returncode == 0 and "DONE" in r.stdout, r.stdout + r.stderr
-    assert "MSG keys replicated over RCCL" in r.stdout, r.stdout + r.stderr
+    assert "MSG transport rccl" in r.stdout, r.stdout + r.stderr
+
+
+def test_multi_context_peer_copy_replication_in_a_fresh_process():
+    """The fallback leg of the key replication (blobs allocated on the other device, then
+    hipMemcpyPeerAsync from the first one), which distinct GPUs take when RCCL is unavailable
+    or fails: the two workers on GPU 0 are treated as sitting on GPUs of their own and RCCL
+    is switched off, so that the allocation-only path and the peer copies run on hardware.
+    A sample handle that outlives its context is then freed without touching it."""
+    code = (
+        "import os, sys\n"
+        f"sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {os.path.join(ROOT, 'tests')!r})\n"
+        "os.environ['TFHE_HIP_MULTI_DISTINCT'] = '1'; os.environ['TFHE_HIP_MULTI_NO_RCCL'] = '1'\n"
+        "import numpy as np, _oracle as orc, tfhe_amd\n"
+        "P = orc.small_params(n=5); K = orc.generate_synthetic_keys(P, 2400)\n"
+        "hp = tfhe_amd.make_params(P.n, n_ks=P.n_ks)\n"
+        "m = tfhe_amd.Engine([0, 0]); print('MSG before', m.key_transport())\n"
+        "m.load_keys(hp, K['bk'], K['ks_a'], K['ks_b'], K['ks_var'])\n"
+        "print('MSG transport', m.key_transport())\n"
+        "ca = (orc.uniform_i32(1, (4, P.n)), orc.uniform_i32(2, (4,)))\n"
+        "oa, ob = m.gate('nand', ca, ca)\n"
+        "for i in range(4):\n"
+        "    wa, wb, _ = orc.gate(P, 'nand', K, (ca[0][i], ca[1][i], 0.0), (ca[0][i], ca[1][i], 0.0))\n"
+        "    assert (oa[i] == wa).all() and ob[i] == wb\n"
+        "h = m.samples_from(*ca)\n"
+        "m.close(); h.free(); print('DONE')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and "DONE" in r.stdout, r.stdout + r.stderr
+    assert "MSG before none" in r.stdout and "MSG transport peer" in r.stdout, r.stdout + r.stderr
 
 
 def test_bench_two_ranks_on_one_gpu():

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TFHE_HIP_LIB") or os.path.join(HERE, "libtfhe_hip.so")
 
 SYMBOLS = [
-    "tfhe_hip_create", "tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_set_stream", "tfhe_hip_set_blind_rotate_mode",
+    "tfhe_hip_create", "tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_key_transport", "tfhe_hip_set_stream", "tfhe_hip_set_blind_rotate_mode",
     "tfhe_hip_circuit_add", "tfhe_hip_circuit_add_dev",
     "tfhe_hip_synchronize", "tfhe_hip_load_keys", "tfhe_hip_key_blob_sizes",
     "tfhe_hip_export_keys_dev", "tfhe_hip_import_keys_dev", "tfhe_hip_bootstrap",
@@ -30,7 +30,7 @@ SYMBOLS = [
     "tfhe_hip_generate_keys", "tfhe_hip_keygen_stream",
     "tfhe_hip_circuit_compare", "tfhe_hip_circuit_compare_dev", "tfhe_hip_circuit_eq", "tfhe_hip_circuit_eq_dev",
 ]
-NO_INT_RESULT = ("tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_samples_free", "tfhe_hip_samples_count")
+NO_INT_RESULT = ("tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_key_transport", "tfhe_hip_samples_free", "tfhe_hip_samples_count")
 
 
 class Params(C.Structure):
@@ -56,6 +56,8 @@ def load():
     lib.tfhe_hip_destroy.restype = None
     lib.tfhe_hip_last_error.argtypes = [vp]
     lib.tfhe_hip_last_error.restype = C.c_char_p
+    lib.tfhe_hip_key_transport.argtypes = [vp]
+    lib.tfhe_hip_key_transport.restype = C.c_char_p
     lib.tfhe_hip_set_stream.argtypes = [vp, vp]
     lib.tfhe_hip_synchronize.argtypes = [vp]
     lib.tfhe_hip_set_blind_rotate_mode.argtypes = [vp, C.c_int]

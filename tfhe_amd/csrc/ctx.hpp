@@ -51,6 +51,11 @@ struct tfhe_hip_ctx {
   // multi-GPU context (tfhe_hip_create_multi): one single-device context per
   // entry of the device list; empty for a single-device context
   std::vector<tfhe_hip_ctx*> shards;
+  // how a multi-GPU context's keys reached its other devices (tfhe_hip_key_transport)
+  const char* key_transport = "none";
+  // sample handles (tfhe_hip_samples_alloc) that still own device memory of this context;
+  // tfhe_hip_destroy releases their buffers and detaches them
+  std::vector<tfhe_hip_samples*> live_handles;
 };
 
 namespace tfhe_detail {
@@ -74,6 +79,11 @@ int load_keys_multi(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, const int3
 
 // keys present on shards[0]: gives every other shard a copy (host_api.cpp)
 int replicate_keys_multi(tfhe_hip_ctx* ctx, const tfhe_hip_params* params);
+// (re)allocates the two device key blobs of a single-device context for `params`, contents
+// undefined, have_keys false until the caller has filled them (tfhe_hip.hip)
+int alloc_key_blobs(tfhe_hip_ctx* ctx, const tfhe_hip_params* params);
+// frees the device memory of the context's live sample handles and detaches them (host_api.cpp)
+void release_handles(tfhe_hip_ctx* ctx);
 
 }  // namespace tfhe_detail
 

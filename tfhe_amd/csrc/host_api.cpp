@@ -569,6 +569,13 @@ int samples_alloc_1(tfhe_hip_ctx* ctx, size_t B, tfhe_hip_samples** out) {
   s->a = (int32_t*)base;
   s->b = (int32_t*)(base + ab);
   s->var = (double*)(base + ab + bb);
+  try {
+    ctx->live_handles.push_back(s);
+  } catch (...) {
+    (void)hipFree(base);
+    delete s;
+    return fail(ctx, TFHE_HIP_ERR_RUNTIME, "out of host memory");
+  }
   *out = s;
   return 0;
 }
@@ -618,7 +625,11 @@ int tfhe_hip_samples_alloc(tfhe_hip_ctx* ctx, size_t B, tfhe_hip_samples** out) 
 void tfhe_hip_samples_free(tfhe_hip_samples* s) {
   if (!s) return;
   for (tfhe_hip_samples* p : s->parts) tfhe_hip_samples_free(p);
+  // s->ctx is NULL once the owning context has been destroyed (release_handles): the
+  // device memory went with the context, only the handle itself is left
   if (s->ctx && s->a) {
+    auto& live = s->ctx->live_handles;
+    live.erase(std::remove(live.begin(), live.end(), s), live.end());
     (void)hipSetDevice(s->ctx->device);
     (void)hipStreamSynchronize(s->ctx->stream);
     (void)hipFree(s->a);
@@ -905,7 +916,38 @@ bool rccl_broadcast_keys(const std::vector<tfhe_hip_ctx*>& leaders) {
   return good;
 }
 
+// dst's blobs (allocated) <- src's, across devices: peer access is enabled where the
+// hardware offers it (the copy then runs over xGMI), otherwise the runtime stages it.
+int peer_copy_keys(tfhe_hip_ctx* dst, const tfhe_hip_ctx* src) {
+  HIP_TRY(dst, hipSetDevice(dst->device));
+  if (dst->device != src->device) {
+    int can = 0;
+    HIP_TRY(dst, hipDeviceCanAccessPeer(&can, dst->device, src->device));
+    if (can) {
+      const hipError_t e = hipDeviceEnablePeerAccess(src->device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+        return fail(dst, TFHE_HIP_ERR_RUNTIME, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+      (void)hipGetLastError();          // "already enabled" is not an error to keep
+    }
+  }
+  HIP_TRY(dst, hipMemcpyPeerAsync(dst->bkfft, dst->device, src->bkfft, src->device, dst->bk_bytes, dst->stream));
+  HIP_TRY(dst, hipMemcpyPeerAsync(dst->ksblob, dst->device, src->ksblob, src->device, dst->ks_bytes, dst->stream));
+  HIP_TRY(dst, hipStreamSynchronize(dst->stream));
+  return 0;
+}
+
 }  // namespace
+
+void tfhe_detail::release_handles(tfhe_hip_ctx* ctx) {
+  for (tfhe_hip_samples* s : ctx->live_handles) {
+    if (s->a) (void)hipFree(s->a);
+    s->a = nullptr;
+    s->b = nullptr;
+    s->var = nullptr;
+    s->ctx = nullptr;
+  }
+  ctx->live_handles.clear();
+}
 
 int tfhe_detail::load_keys_multi(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, const int32_t* bk,
                                  const int32_t* ks_a, const int32_t* ks_b, const double* ks_var) {
@@ -924,25 +966,31 @@ int tfhe_detail::replicate_keys_multi(tfhe_hip_ctx* ctx, const tfhe_hip_params* 
   std::vector<int> leader_of(sh.size(), 0);
   for (size_t r = 0; r < sh.size(); r++) {
     int found = -1;
-    for (size_t k = 0; k < leaders.size(); k++)
-      if (leaders[k]->device == sh[r]->device) found = (int)k;
+    if (getenv("TFHE_HIP_MULTI_DISTINCT") == nullptr)
+      for (size_t k = 0; k < leaders.size(); k++)
+        if (leaders[k]->device == sh[r]->device) found = (int)k;
     if (found < 0) {
       found = (int)leaders.size();
       leaders.push_back(sh[r]);
     }
     leader_of[r] = found;
   }
+  // Test switches: FORCE_RCCL runs the broadcast even on a one-GPU communicator, NO_RCCL
+  // skips it, DISTINCT treats every worker as if it sat on a GPU of its own (so that the
+  // cross-device legs run on a one-GPU box).
   const bool force_rccl = getenv("TFHE_HIP_MULTI_FORCE_RCCL") != nullptr;
+  ctx->key_transport = "local";
   if (leaders.size() > 1 || force_rccl) {
-    // The other leaders adopt blobs of the right size (contents replaced by the
-    // broadcast); importing from the first device's blobs allocates them and, should
-    // RCCL be unavailable, is already the peer-to-peer copy.
-    bool done = false;
+    // the other leaders get blobs of the right size, contents arrive below: once
     for (size_t k = 1; k < leaders.size(); k++)
-      if (int rc = tfhe_hip_import_keys_dev(leaders[k], params, sh[0]->bkfft, sh[0]->ksblob))
-        return fail(ctx, rc, leaders[k]->err);
+      if (int rc = alloc_key_blobs(leaders[k], params)) return fail(ctx, rc, leaders[k]->err);
+    bool done = false;
     if (getenv("TFHE_HIP_MULTI_NO_RCCL") == nullptr) done = rccl_broadcast_keys(leaders);
-    ctx->err = done ? "keys replicated over RCCL" : "keys replicated by peer-to-peer copies";
+    if (!done)
+      for (size_t k = 1; k < leaders.size(); k++)
+        if (int rc = peer_copy_keys(leaders[k], sh[0])) return fail(ctx, rc, leaders[k]->err);
+    for (size_t k = 1; k < leaders.size(); k++) leaders[k]->have_keys = true;
+    ctx->key_transport = done ? "rccl" : "peer";
   }
   // the remaining contexts copy from the leader on their own GPU
   for (size_t r = 0; r < sh.size(); r++) {
@@ -953,6 +1001,10 @@ int tfhe_detail::replicate_keys_multi(tfhe_hip_ctx* ctx, const tfhe_hip_params* 
   ctx->P = *params;
   ctx->have_keys = true;
   return 0;
+}
+
+extern "C" const char* tfhe_hip_key_transport(tfhe_hip_ctx* ctx) {
+  return ctx && ctx->have_keys ? ctx->key_transport : "none";
 }
 
 extern "C" int tfhe_hip_create_multi(tfhe_hip_ctx** out, const int* devices, int ndev) {

@@ -1613,6 +1613,12 @@ int tfhe_detail::need_keys(tfhe_hip_ctx* ctx) {
   return 0;
 }
 
+int tfhe_detail::alloc_key_blobs(tfhe_hip_ctx* ctx, const tfhe_hip_params* p) {
+  if (int rc = check_params(ctx, p)) return rc;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  return alloc_keys(ctx, p);
+}
+
 namespace {
 using tfhe_detail::need_keys;
 
@@ -1769,6 +1775,8 @@ void tfhe_hip_destroy(tfhe_hip_ctx* ctx) {
     return;
   }
   (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  tfhe_detail::release_handles(ctx);
   if (ctx->tables) (void)hipFree(ctx->tables);
   if (ctx->bkfft) (void)hipFree(ctx->bkfft);
   if (ctx->ksblob) (void)hipFree(ctx->ksblob);
@@ -2010,8 +2018,14 @@ int tfhe_hip_generate_keys(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, dou
     if (ks_a_out) HIP_TRY(c, hipMemcpyAsync(ks_a_out, da.p, z.ks_a, hipMemcpyDeviceToHost, c->stream));
     if (ks_b_out) HIP_TRY(c, hipMemcpyAsync(ks_b_out, db.p, z.ks_b, hipMemcpyDeviceToHost, c->stream));
     if (ks_var_out) HIP_TRY(c, hipMemcpyAsync(ks_var_out, dv.p, z.ks_var, hipMemcpyDeviceToHost, c->stream));
-    return keys_from_device(c, params, (const int32_t*)dbk.p, (const int32_t*)da.p, (const int32_t*)db.p,
-                            (const double*)dv.p);
+    if (int rc = keys_from_device(c, params, (const int32_t*)dbk.p, (const int32_t*)da.p, (const int32_t*)db.p,
+                                  (const double*)dv.p)) return rc;
+    // the secret keys and the noises do not outlive the call in device memory
+    HIP_TRY(c, hipMemsetAsync(dkey.p, 0, (size_t)P.n * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(dtkey.p, 0, (size_t)tlwe_count * 4, c->stream));
+    HIP_TRY(c, hipMemsetAsync(dnoise.p, 0, (size_t)size_ks * 8, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return 0;
   };
   if (int rc = run()) return c == ctx ? rc : fail(ctx, rc, c->err);
   if (c != ctx) return tfhe_detail::replicate_keys_multi(ctx, params);
@@ -2150,8 +2164,11 @@ int tfhe_hip_gate_dev_noalloc(tfhe_hip_ctx* ctx, int gate, const int32_t* ca_a, 
 int tfhe_hip_polymul_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, int32_t* out,
                          int accumulate, size_t B) {
   if (!ctx) return TFHE_HIP_ERR_ARG;
+  if (!ctx->shards.empty())
+    return fail(ctx, TFHE_HIP_ERR_ARG, "device-pointer entry points need a single-device context");
   if (B == 0) return 0;
   if (!d || !s || !out) return fail(ctx, TFHE_HIP_ERR_ARG, "polynomial pointer is NULL");
+  if (B > (size_t)INT32_MAX) return fail(ctx, TFHE_HIP_ERR_ARG, "batch too large");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   const size_t pairs = (B + 1) / 2;
   const unsigned grid = (unsigned)std::min<size_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock,

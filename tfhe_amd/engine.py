@@ -58,9 +58,10 @@ class Samples:
             self.handle = C.c_void_p()
 
     def __del__(self):
+        # safe after Engine.close(): destroying a context releases the device memory of its
+        # live handles, the free that follows only deletes the handle
         try:
-            if self.engine.ctx:
-                self.free()
+            self.free()
         except Exception:
             pass
 
@@ -112,6 +113,10 @@ class Engine:
 
     def last_message(self):
         return self.lib.tfhe_hip_last_error(self.ctx).decode()
+
+    def key_transport(self):
+        """How a multi-GPU context's keys reached its other devices: rccl / peer / local / none."""
+        return self.lib.tfhe_hip_key_transport(self.ctx).decode()
 
     # ---- keys -----------------------------------------------------------------
     @staticmethod

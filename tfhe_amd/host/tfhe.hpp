@@ -141,20 +141,30 @@ struct Device {
 
 }  // namespace detail
 
-// CloudKey (src/lwe.rs:247-257) with its LweBootstrappingKey (src/lwe.rs:432-446)
-// flattened the way tfhe_hip_load_keys takes it.
-struct CloudKey {
-  Parameters params;
+// LweKeySwitchKey (src/lwe.rs:495-514) with ks[i][j][h] flattened the way tfhe_hip_load_keys
+// takes it.
+struct LweKeySwitchKey {
+  int32_t n = 0, t = 0, base_bit = 0;   // rows (the in/out n, src/lwe.rs:461), digits, log2(base)
+  std::vector<int32_t> a;               // [n][t][base][n_out]  ks[i][j][h].coefficients
+  std::vector<int32_t> b;               // [n][t][base]         ks[i][j][h].b
+  std::vector<double> var;              // [n][t][base]         ks[i][j][h].current_variance
+};
+
+// LweBootstrappingKey (src/lwe.rs:432-446): the parameters the path reads, the TGSW samples
+// flattened the way tfhe_hip_load_keys takes them, the key-switch key, and the GPU context
+// that holds the uploaded key.  The context hangs here, not on CloudKey, because
+// tfhe_bootstrap(bk: &LweBootstrappingKey, ..) (src/bootstrapping.rs:25) sees only this.
+struct LweBootstrappingKey {
+  LweParams in_out_params{};
+  TGswParams bk_params{};
   std::vector<int32_t> bk;      // [n][l][k+1][k+1][N]
-  std::vector<int32_t> ks_a;    // [n][t][base][n]
-  std::vector<int32_t> ks_b;    // [n][t][base]
-  std::vector<double> ks_var;   // [n][t][base]
+  LweKeySwitchKey ks;
   std::shared_ptr<detail::Device> device;
 
   tfhe_hip_params hip_params() const {
-    const auto& g = params.tgsw_params;
-    return tfhe_hip_params{params.in_out_params.n, g.tlwe_params.n, g.tlwe_params.k, g.l, g.bg_bit,
-                           params.ks_t, params.ks_base_bit, params.in_out_params.n};
+    const auto& g = bk_params;
+    return tfhe_hip_params{in_out_params.n, g.tlwe_params.n, g.tlwe_params.k, g.l, g.bg_bit,
+                           ks.t, ks.base_bit, ks.n};
   }
   // Uploads the key material to GPU `device_index` (done by generate_keys).
   void upload(int device_index = 0) {
@@ -166,6 +176,36 @@ struct CloudKey {
     device = std::make_shared<detail::Device>(devices);
     load();
   }
+  const detail::Device& on_device() const {
+    if (!device) throw std::runtime_error("LweBootstrappingKey has no device context");
+    return *device;
+  }
+
+ private:
+  void load() {
+    tfhe_hip_params hp = hip_params();
+    device->check(tfhe_hip_load_keys(device->ctx, &hp, bk.data(), ks.a.data(), ks.b.data(), ks.var.data()));
+  }
+};
+
+// CloudKey (src/lwe.rs:247-257): the parameters and the bootstrapping key.
+struct CloudKey {
+  Parameters params;
+  LweBootstrappingKey bk;
+
+  static CloudKey with_params(const Parameters& params) {     // CloudKey::new + LweBootstrappingKey::new
+    CloudKey ck;
+    ck.params = params;
+    ck.bk.in_out_params = params.in_out_params;
+    ck.bk.bk_params = params.tgsw_params;
+    ck.bk.ks.n = params.in_out_params.n;                      // src/lwe.rs:461
+    ck.bk.ks.t = params.ks_t;
+    ck.bk.ks.base_bit = params.ks_base_bit;
+    return ck;
+  }
+  tfhe_hip_params hip_params() const { return bk.hip_params(); }
+  void upload(int device_index = 0) { bk.upload(device_index); }
+  void upload(const std::vector<int>& devices) { bk.upload(devices); }
   // The key file of tfhe_hip_key_file_pack (the crate derives Serialize for CloudKey,
   // src/lwe.rs:247-251, without fixing a byte format).
   std::vector<unsigned char> to_bytes() const {
@@ -173,24 +213,18 @@ struct CloudKey {
     size_t bytes = 0;
     if (tfhe_hip_key_file_size(&hp, 1, &bytes) != 0) throw std::runtime_error("tfhe_hip_key_file_size failed");
     std::vector<unsigned char> out(bytes);
-    if (tfhe_hip_key_file_pack(&hp, bk.data(), ks_a.data(), ks_b.data(), ks_var.data(), out.data(), bytes) != 0)
+    if (tfhe_hip_key_file_pack(&hp, bk.bk.data(), bk.ks.a.data(), bk.ks.b.data(), bk.ks.var.data(), out.data(),
+                               bytes) != 0)
       throw std::runtime_error("tfhe_hip_key_file_pack failed");
     return out;
   }
   // A CloudKey for gates only (the flat key arrays stay empty) from a key file image.
   static CloudKey from_bytes(const Parameters& params, const std::vector<unsigned char>& image,
                              int device_index = 0) {
-    CloudKey ck;
-    ck.params = params;
-    ck.device = std::make_shared<detail::Device>(device_index);
-    ck.device->check(tfhe_hip_load_keys_blob(ck.device->ctx, image.data(), image.size()));
+    CloudKey ck = with_params(params);
+    ck.bk.device = std::make_shared<detail::Device>(device_index);
+    ck.bk.device->check(tfhe_hip_load_keys_blob(ck.bk.device->ctx, image.data(), image.size()));
     return ck;
-  }
-
- private:
-  void load() {
-    tfhe_hip_params hp = hip_params();
-    device->check(tfhe_hip_load_keys(device->ctx, &hp, bk.data(), ks_a.data(), ks_b.data(), ks_var.data()));
   }
 };
 
@@ -213,13 +247,12 @@ inline std::pair<SecretKey, CloudKey> generate_keys(const Parameters& params, in
   std::vector<int32_t> tlwe_key((size_t)(k + 1) * N);
   for (auto& v : tlwe_key) v = rng.bit();
 
-  CloudKey ck;
-  ck.params = params;
+  CloudKey ck = CloudKey::with_params(params);
   // key-switch key: rows for the first n coefficients of the extracted key (src/lwe.rs:461)
   const size_t rows = (size_t)n * t * base;
-  ck.ks_a.assign(rows * n, 0);
-  ck.ks_b.assign(rows, 0);
-  ck.ks_var.assign(rows, 0.0);
+  ck.bk.ks.a.assign(rows * n, 0);
+  ck.bk.ks.b.assign(rows, 0);
+  ck.bk.ks.var.assign(rows, 0.0);
   {
     const double alpha = params.in_out_params.alpha_min;
     const int size_ks = n * t * (base - 1);
@@ -236,18 +269,18 @@ inline std::pair<SecretKey, CloudKey> generate_keys(const Parameters& params, in
           Torus32 b = wadd(message, f64_to_torus_32(noise[index++] - error));
           for (int x = 0; x < n; x++) {
             const int32_t a = rng.torus();
-            ck.ks_a[idx * n + x] = a;
+            ck.bk.ks.a[idx * n + x] = a;
             b = wadd(b, wmul(a, sk.lwe_key[x]));
           }
-          ck.ks_b[idx] = b;
-          ck.ks_var[idx] = alpha * alpha;
+          ck.bk.ks.b[idx] = b;
+          ck.bk.ks.var[idx] = alpha * alpha;
         }
   }
   // bootstrapping key
   const double alpha = params.tgsw_params.tlwe_params.alpha_min;
-  ck.bk.assign((size_t)n * l * (k + 1) * (k + 1) * N, 0);
+  ck.bk.bk.assign((size_t)n * l * (k + 1) * (k + 1) * N, 0);
   for (int i = 0; i < n; i++) {
-    int32_t* s = ck.bk.data() + (size_t)i * l * (k + 1) * (k + 1) * N;
+    int32_t* s = ck.bk.bk.data() + (size_t)i * l * (k + 1) * (k + 1) * N;
     for (int j = 0; j <= k; j++) {                    // row 0 only (src/tgsw.rs:118-127)
       int32_t* smp = s + (size_t)j * (k + 1) * N;
       for (int u = 0; u < k; u++)
@@ -270,7 +303,10 @@ inline std::pair<SecretKey, CloudKey> generate_keys(const Parameters& params, in
 
 // generate_keys with the randomness drawn on the GPU (tfhe_hip_generate_keys): the same key
 // structure, every value a function of `seed` (32 bytes, the ChaCha20 key), so a seed
-// reproduces its keys.  Use operating-system entropy for real keys.
+// reproduces its keys.  As with the crate's own generate_keys, the cloud key this returns
+// carries the LWE secret key bits in the clear (coefficient 0 of the row-0 polynomials is
+// key bit * l plus nothing, src/tgsw.rs:129-167 applied to an all-zero body): a parity and
+// benchmark fixture, not key material to protect data with.
 inline std::pair<SecretKey, CloudKey> generate_keys_gpu(const Parameters& params, const uint8_t seed[32],
                                                         int device_index = 0) {
   const int32_t n = params.in_out_params.n, N = params.tgsw_params.tlwe_params.n;
@@ -278,18 +314,17 @@ inline std::pair<SecretKey, CloudKey> generate_keys_gpu(const Parameters& params
   const size_t rows = (size_t)n * params.ks_t * ((size_t)1 << params.ks_base_bit);
   SecretKey sk{params, std::vector<int32_t>(n)};
   std::vector<int32_t> tlwe_key((size_t)(k + 1) * N);
-  CloudKey ck;
-  ck.params = params;
-  ck.bk.resize((size_t)n * l * (k + 1) * (k + 1) * N);
-  ck.ks_a.resize(rows * n);
-  ck.ks_b.resize(rows);
-  ck.ks_var.resize(rows);
-  ck.device = std::make_shared<detail::Device>(device_index);
+  CloudKey ck = CloudKey::with_params(params);
+  ck.bk.bk.resize((size_t)n * l * (k + 1) * (k + 1) * N);
+  ck.bk.ks.a.resize(rows * n);
+  ck.bk.ks.b.resize(rows);
+  ck.bk.ks.var.resize(rows);
+  ck.bk.device = std::make_shared<detail::Device>(device_index);
   tfhe_hip_params hp = ck.hip_params();
-  ck.device->check(tfhe_hip_generate_keys(ck.device->ctx, &hp, params.in_out_params.alpha_min,
-                                          params.tgsw_params.tlwe_params.alpha_min, seed, sk.lwe_key.data(),
-                                          tlwe_key.data(), ck.bk.data(), ck.ks_a.data(), ck.ks_b.data(),
-                                          ck.ks_var.data()));
+  ck.bk.device->check(tfhe_hip_generate_keys(ck.bk.device->ctx, &hp, params.in_out_params.alpha_min,
+                                             params.tgsw_params.tlwe_params.alpha_min, seed, sk.lwe_key.data(),
+                                             tlwe_key.data(), ck.bk.bk.data(), ck.bk.ks.a.data(),
+                                             ck.bk.ks.b.data(), ck.bk.ks.var.data()));
   return {std::move(sk), std::move(ck)};
 }
 
@@ -343,7 +378,7 @@ namespace detail {
 inline std::vector<LweSample> gate_batch(int gate, const std::vector<LweSample>& a,
                                          const std::vector<LweSample>& b,
                                          const std::vector<LweSample>* c, const CloudKey& bk) {
-  if (!bk.device) throw std::runtime_error("CloudKey has no device context");
+  const detail::Device& dev = bk.bk.on_device();
   const size_t B = a.size(), n = bk.params.in_out_params.n;
   if (b.size() != B || (c && c->size() != B)) throw std::runtime_error("gate: batch sizes differ");
   auto pack = [&](const std::vector<LweSample>& v, std::vector<int32_t>& m, std::vector<int32_t>& body) {
@@ -360,9 +395,9 @@ inline std::vector<LweSample> gate_batch(int gate, const std::vector<LweSample>&
   pack(a, aa, ab);
   pack(b, ba, bb);
   if (c) pack(*c, ca, cb);
-  bk.device->check(tfhe_hip_gate(bk.device->ctx, gate, aa.data(), ab.data(), ba.data(), bb.data(),
-                                 c ? ca.data() : nullptr, c ? cb.data() : nullptr, oa.data(),
-                                 ob.data(), var.data(), B));
+  dev.check(tfhe_hip_gate(dev.ctx, gate, aa.data(), ab.data(), ba.data(), bb.data(),
+                          c ? ca.data() : nullptr, c ? cb.data() : nullptr, oa.data(), ob.data(),
+                          var.data(), B));
   std::vector<LweSample> out(B);
   for (size_t i = 0; i < B; i++) {
     out[i].coefficients.assign(oa.begin() + i * n, oa.begin() + (i + 1) * n);
@@ -404,15 +439,16 @@ inline LweSample mux(const LweSample& a, const LweSample& b, const LweSample& c,
   return detail::gate_batch(TFHE_HIP_MUX, {a}, {b}, &cc, bk)[0];
 }
 
-// src/bootstrapping.rs:25-29
-inline LweSample tfhe_bootstrap(const CloudKey& bk, Torus32 mu, const LweSample& x) {
-  if (!bk.device) throw std::runtime_error("CloudKey has no device context");
-  const size_t n = bk.params.in_out_params.n;
+// src/bootstrapping.rs:25-29: tfhe_bootstrap(bk: &LweBootstrappingKey, mu, x); the crate's
+// callers pass &cloud_key.bk (src/gates.rs:35, benches/bootstrapping.rs:21).
+inline LweSample tfhe_bootstrap(const LweBootstrappingKey& bk, Torus32 mu, const LweSample& x) {
+  const detail::Device& dev = bk.on_device();
+  const size_t n = bk.in_out_params.n;
   if (x.coefficients.size() != n) throw std::runtime_error("tfhe_bootstrap: sample size differs from n");
   LweSample out;
   out.coefficients.resize(n);
-  bk.device->check(tfhe_hip_bootstrap(bk.device->ctx, mu, x.coefficients.data(), &x.b,
-                                      out.coefficients.data(), &out.b, &out.current_variance, 1));
+  dev.check(tfhe_hip_bootstrap(dev.ctx, mu, x.coefficients.data(), &x.b, out.coefficients.data(), &out.b,
+                               &out.current_variance, 1));
   return out;
 }
 
@@ -442,7 +478,7 @@ inline void bit_slice(const std::vector<std::vector<LweSample>>& x, size_t bits,
 template <class Fn>
 inline std::vector<LweSample> reduce(Fn fn, const char* what, const std::vector<std::vector<LweSample>>& a,
                                      const std::vector<std::vector<LweSample>>& b, const CloudKey& key) {
-  if (!key.device) throw std::runtime_error("CloudKey has no device context");
+  const ::tfhe::detail::Device& dev = key.bk.on_device();
   if (a.size() != b.size()) throw std::runtime_error(std::string(what) + ": numbers of operands differ");
   const size_t count = a.size(), n = key.params.in_out_params.n;
   if (count == 0) return {};
@@ -452,7 +488,7 @@ inline std::vector<LweSample> reduce(Fn fn, const char* what, const std::vector<
   bit_slice(b, bits, n, what, ba, bb);
   std::vector<int32_t> oa(count * n), ob(count);
   std::vector<double> ov(count);
-  key.device->check(fn(key.device->ctx, aa.data(), ab.data(), ba.data(), bb.data(), oa.data(), ob.data(),
+  dev.check(fn(dev.ctx, aa.data(), ab.data(), ba.data(), bb.data(), oa.data(), ob.data(),
                        ov.data(), count, (int)bits));
   std::vector<LweSample> out(count);
   for (size_t c = 0; c < count; c++) {
@@ -520,7 +556,7 @@ inline std::pair<LweSample, LweSample> full_adder(const LweSample& a, const LweS
 inline std::vector<std::pair<std::vector<LweSample>, LweSample>> add(
     const std::vector<std::vector<LweSample>>& a, const std::vector<std::vector<LweSample>>& b,
     const CloudKey& key) {
-  if (!key.device) throw std::runtime_error("CloudKey has no device context");
+  const ::tfhe::detail::Device& dev = key.bk.on_device();
   if (a.size() != b.size()) throw std::runtime_error("add: numbers of operands differ");
   const size_t count = a.size(), n = key.params.in_out_params.n;
   if (count == 0) return {};
@@ -540,7 +576,7 @@ inline std::vector<std::pair<std::vector<LweSample>, LweSample>> add(
   }
   std::vector<int32_t> sa(aa.size()), sb(ab.size()), ca(count * n), cb(count);
   std::vector<double> sv(ab.size()), cv(count);
-  key.device->check(tfhe_hip_circuit_add(key.device->ctx, aa.data(), ab.data(), ba.data(), bb.data(),
+  dev.check(tfhe_hip_circuit_add(dev.ctx, aa.data(), ab.data(), ba.data(), bb.data(),
                                          sa.data(), sb.data(), ca.data(), cb.data(), sv.data(), cv.data(),
                                          count, (int)bits));
   std::vector<std::pair<std::vector<LweSample>, LweSample>> out(count);
