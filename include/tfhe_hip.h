@@ -100,13 +100,19 @@ int tfhe_hip_set_stream(tfhe_hip_ctx* ctx, void* hip_stream);
 int tfhe_hip_synchronize(tfhe_hip_ctx* ctx);
 
 /* How tfhe_blind_rotate (src/bootstrapping.rs:109-134) is mapped to the GPU.
- * BATCH: one ciphertext per wavefront, persistent workgroups (throughput form).
- * SPLIT: one ciphertext per workgroup, one wavefront per (decomposition level,
- *        result polynomial) pair of tgsw_extern_mul_to_tlwe (src/tgsw.rs:229-264);
- *        a third of the latency, 4/3 of the arithmetic.
- * AUTO (default): SPLIT while the batch has at most two ciphertexts per
- *        compute unit, BATCH above.  Results are identical in every mode. */
-enum { TFHE_HIP_BR_AUTO = 0, TFHE_HIP_BR_BATCH = 1, TFHE_HIP_BR_SPLIT = 2 };
+ * BATCH:   one ciphertext per wavefront, one wavefront per SIMD; a transform takes a
+ *          half-wave, the two digit polynomials of a level run side by side.
+ * BATCH64: one ciphertext per wavefront, two wavefronts per SIMD; a transform takes
+ *          the whole wavefront, the two digit polynomials run one after the other.
+ *          Both are throughput forms with persistent workgroups.
+ * SPLIT:   one ciphertext per workgroup, one wavefront per (decomposition level,
+ *          result polynomial) pair of tgsw_extern_mul_to_tlwe (src/tgsw.rs:229-264);
+ *          a third of the latency, 4/3 of the arithmetic.
+ * AUTO (default): SPLIT while the batch has at most two ciphertexts per compute
+ *          unit; above that whichever throughput form measured faster on MI355X
+ *          for the parameter set (l = 2: BATCH64, l = 3: BATCH).
+ * Results are identical in every mode. */
+enum { TFHE_HIP_BR_AUTO = 0, TFHE_HIP_BR_BATCH = 1, TFHE_HIP_BR_SPLIT = 2, TFHE_HIP_BR_BATCH64 = 3 };
 int tfhe_hip_set_blind_rotate_mode(tfhe_hip_ctx* ctx, int mode);
 
 /* Per-kernel timing with HIP events on the context's stream.  While enabled,

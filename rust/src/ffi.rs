@@ -49,6 +49,7 @@ pub const MUX: c_int = 10;
 pub const BR_AUTO: c_int = 0;
 pub const BR_BATCH: c_int = 1;
 pub const BR_SPLIT: c_int = 2;
+pub const BR_BATCH64: c_int = 3;
 
 extern "C" {
     pub fn tfhe_hip_create(out: *mut *mut TfheHipCtx, device: c_int) -> c_int;

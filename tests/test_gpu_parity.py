@@ -15,10 +15,11 @@ pytestmark = pytest.mark.gpu
 SHAPES = {"l2": (2, 10), "l3": (3, 7)}
 
 
-@pytest.fixture(scope="module", params=["batch", "split"])
+@pytest.fixture(scope="module", params=["batch", "batch64", "split"])
 def eng(request):
-    """Every test runs against both mappings of the blind rotation (one
-    ciphertext per wavefront / per workgroup); results must be identical."""
+    """Every test runs against all three mappings of the blind rotation (one ciphertext per
+    wavefront with one or with two wavefronts per SIMD / one per workgroup); results must be
+    identical."""
     import tfhe_amd
     e = tfhe_amd.Engine(0)
     e.set_blind_rotate_mode(request.param)
@@ -308,12 +309,12 @@ def test_blind_rotate_mappings_agree_at_full_size(level):
     e = tfhe_amd.Engine(0)
     try:
         _load(e, P, K)
-        for mode in ("batch", "split", "auto"):
+        for mode in ("batch", "batch64", "split", "auto"):
             e.set_blind_rotate_mode(mode)
             out[mode] = e.gate("xor", ca, cb, want_var=True)
     finally:
         e.close()
-    for mode in ("split", "auto"):
+    for mode in ("batch64", "split", "auto"):
         for x, y in zip(out["batch"], out[mode]):
             assert (x == y).all(), mode
     # and two ciphertexts of the batch against the oracle

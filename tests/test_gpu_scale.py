@@ -139,7 +139,7 @@ def test_extprod_rounding_margin_full_size_keys(eng, level):
 
 # ---- blind-rotate hook: any i32 rotation amount ---------------------------------------
 
-@pytest.mark.parametrize("mode", ["batch", "split"])
+@pytest.mark.parametrize("mode", ["batch", "batch64", "split"])
 @pytest.mark.parametrize("tag", [(2, 10), (3, 7)])
 def test_blind_rotate_hook_any_power(mode, tag):
     """mul_by_monomial reduces its power with (power / N) mod 2 and power % N

@@ -14,7 +14,7 @@ COMMON_DEPS = [os.path.join(CSRC, "ctx.hpp"), HEADER]
 UNITS = [
     # (source, object, extra dependencies, extra flags)
     (os.path.join(CSRC, "tfhe_hip.hip"), os.path.join(CSRC, "tfhe_hip.o"),
-     [os.path.join(CSRC, "wave_fft.hpp")],
+     [os.path.join(CSRC, "wave_fft.hpp"), os.path.join(CSRC, "wave_fft64.hpp")],
      # max-ilp scheduling: one wavefront per SIMD has nobody to hide a dependent
      # instruction's latency behind, so independent work is interleaved by the compiler
      ["--offload-arch=gfx950", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]),

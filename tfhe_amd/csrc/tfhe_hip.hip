@@ -17,6 +17,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -25,6 +26,7 @@
 
 #include "ctx.hpp"
 #include "wave_fft.hpp"
+#include "wave_fft64.hpp"
 
 using wfft::cplx;
 using wfft::static_for;
@@ -263,7 +265,7 @@ __device__ __forceinline__ void level_product(int p, const char* tt, const cplx*
 struct NoMargin {
   __device__ __forceinline__ void track(double) {}
 };
-// Largest |x - rint(x)| seen before rounding (see polymul_kernel).
+// Largest |x - rint(x)| seen before rounding (see polymul64_kernel).
 struct Margin {
   double all = 0.0, deciding = 0.0;
   __device__ __forceinline__ void track(double x) {
@@ -428,6 +430,8 @@ struct BlindRotateArgs {
   const int32_t* barb;      // [B]      mod-switched body (bootstrap mode)
   const cplx* bkfft;        // [n][l][2][32][64]
   const cplx* tables;       // make_tables: two pairs of 1024-entry tables
+  const cplx* tables64;     // make_tables64
+  int32_t* prev_ws;         // blind_rotate64_kernel: [wavefront slots][2][N] previous accumulators
   int32_t* acc_io;          // hook mode: [B][3][N] accumulators, updated in place
   int32_t* out_a;           // bootstrap mode: [B][N] extracted mask
   int32_t* out_b;           // bootstrap mode: [B]
@@ -764,158 +768,362 @@ __global__ __launch_bounds__(kBlock, 1) void bk_fft_kernel(const int32_t* __rest
   });
 }
 
-// poly_multiplier / torus_polynomial_mul_r on independent pairs.  One half-wave per product:
-// the twisted transforms of d and s (wave_fft.hpp), their pointwise product, and one inverse
-// transform whose untwisted real part is the low half of the linear convolution and whose
-// negated imaginary part is the high half.  The two half-waves of a wavefront work on two
-// products in the same instructions and never exchange data.
-//   * the spectrum of d waits in the accumulation registers while s is transformed;
-//   * the operands of the NEXT pair of products are copied global -> LDS by the DMA path
-//     (global_load_lds, no registers) as soon as this pair's operands have been read.
+// poly_multiplier / torus_polynomial_mul_r (src/numerics.rs:138-155,185-261) on independent
+// pairs, one product per WAVEFRONT (wave_fft64.hpp): the twisted transforms of d and s, their
+// pointwise product, and one inverse transform whose untwisted real part is the low half of the
+// linear convolution and whose negated imaginary part is the high half.  A wavefront needs 16
+// complex registers for a transform and as many for the spectrum of d that waits while s is
+// transformed, so two wavefronts share a SIMD and one's LDS round trips hide behind the other's
+// arithmetic.  Eight wavefronts per workgroup, persistent; the operands of the NEXT product are
+// copied global -> LDS by the DMA path (global_load_lds, no registers) as soon as this
+// product's operands have been read.
 //
-// MARGIN (test hook): nothing is written to out; margin [B][2] receives, per
-// product, the largest |x - rint(x)| over all 2N-1 coefficients before rounding
-// and the largest over the coefficients whose rounding decides the result
-// (|rint(x)| <= 2^31; beyond that the cast saturates whatever the fraction is).
+// MARGIN (test hook): nothing is written to out; margin [B][2] receives, per product, the
+// largest |x - rint(x)| over all 2N-1 coefficients before rounding and the largest over the
+// coefficients whose rounding decides the result (|rint(x)| <= 2^31; beyond that the cast
+// saturates whatever the fraction is).
 typedef __attribute__((address_space(3))) void* lds_dma_ptr;
 
+constexpr int kWaves64 = 8;
+constexpr int kStage64Bytes = 2 * kN * 4;                                  // d | s of one product
+constexpr int kWave64Bytes = wfft64::kTileBytes + kStage64Bytes;
+constexpr int kLds64Bytes = kWaves64 * kWave64Bytes + wfft64::kTableBytes;
+
+__device__ __forceinline__ wfft64::Tables load_tables64(char* lds_tables, const cplx* __restrict__ tables64) {
+  cplx* dst = reinterpret_cast<cplx*>(lds_tables);
+  for (int i = threadIdx.x; i < wfft64::kT1Entries + wfft64::kT2Entries; i += blockDim.x) dst[i] = tables64[i];
+  __syncthreads();
+  return {dst, dst + wfft64::kT1Entries};
+}
+
 template <bool ACCUMULATE, bool MARGIN>
-__global__ __launch_bounds__(kBlock, 1) void polymul_kernel(const int32_t* __restrict__ d,
-                                                            const int32_t* __restrict__ s,
-                                                            const cplx* __restrict__ tables,
-                                                            int32_t* __restrict__ out,
-                                                            double* __restrict__ margin, int B) {
-  __shared__ __attribute__((aligned(16))) char lds[kLdsBytes];
-  char* lds_tables = lds + kWavesPerBlock * wfft::kWaveBytes;
-  load_tables<kPolymulScalar>(lds_tables, tables);
-  const cplx* tE = reinterpret_cast<const cplx*>(lds_tables);
-  const cplx* tq = tE + 1024;
+__global__ __launch_bounds__(64 * kWaves64) void polymul64_kernel(const int32_t* __restrict__ d,
+                                                                  const int32_t* __restrict__ s,
+                                                                  const cplx* __restrict__ tables64,
+                                                                  int32_t* __restrict__ out,
+                                                                  double* __restrict__ margin, int B) {
+  __shared__ __attribute__((aligned(16))) char lds[kLds64Bytes];
+  const wfft64::Tables tb = load_tables64(lds + kWaves64 * kWave64Bytes, tables64);
   const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* wave_tiles = lds + wave * wfft::kWaveBytes;
-  char* stage = wave_tiles + wfft::kExchangeBytes;       // the operands of one pair of products
-  const int stride = gridDim.x * kWavesPerBlock;
+  char* tile = lds + wave * kWave64Bytes;
+  char* stage = tile + wfft64::kTileBytes;
+  const int stride = gridDim.x * kWaves64;
 
-  // operands of pair `pair` -> stage: [d_a | d_b | s_a | s_b], 4 KiB each, coefficient order;
-  // a missing second product reads the first one again (its results are not stored)
-  auto fetch = [&](int pair, int lane) WFFT_INLINE {
-    const int ia = 2 * pair, ib = (2 * pair + 1 < B) ? 2 * pair + 1 : ia;
-    const int32_t* src[4] = {d + (size_t)ia * kN, d + (size_t)ib * kN, s + (size_t)ia * kN, s + (size_t)ib * kN};
-    static_for<0, 16>([&](auto ic) WFFT_INLINE {
+  auto fetch = [&](int prod, int lane) WFFT_INLINE {
+    const int32_t* src[2] = {d + (size_t)prod * kN, s + (size_t)prod * kN};
+    static_for<0, 8>([&](auto ic) WFFT_INLINE {
       constexpr int i = decltype(ic)::value;
       __builtin_amdgcn_global_load_lds((const void*)(src[i >> 2] + (i & 3) * 256 + lane * 4),
                                        (lds_dma_ptr)(stage + i * 1024), 16, 0, 0);
     });
   };
 
-  int pair = blockIdx.x * kWavesPerBlock + wave;
-  if (2 * pair < B) fetch(pair, lane0);
-  StampCtx st;
-  st.start();
+  int prod = blockIdx.x * kWaves64 + wave;
+  if (prod < B) fetch(prod, lane0);
 #pragma unroll 1
-  for (; 2 * pair < B; pair += stride) {
-    const int ia = 2 * pair, ib = 2 * pair + 1;
-    const bool has_b = ib < B;
-    // Lane-derived addresses are recomputed per phase (a handful of instructions) instead of
-    // being kept live, or spilled, across the loop.
+  for (; prod < B; prod += stride) {
     auto fresh_lane = [&]() WFFT_INLINE {
       int l = lane0;
       asm volatile("" : "+v"(l));
       return l;
     };
-    double re[32], im[32];
-    unsigned park[128];      // spectrum of d, parked in accumulation registers
-    TFHE_STAMP(st, 0);
+    double re[16], im[16];
+    double pre[16], pim[16]; // spectrum of d, waiting while s is transformed
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the operands have landed
-    TFHE_STAMP(st, 1);
     {
-      const int lane = fresh_lane(), h = lane >> 5, q = lane & 31;
-      const int32_t* in = reinterpret_cast<const int32_t*>(stage) + h * kN + q;
-      wfft::chunked_for32<8>([&](auto ic) WFFT_INLINE {
+      const int lane = fresh_lane();
+      const int32_t* in = reinterpret_cast<const int32_t*>(stage) + lane;
+      static_for<0, 16>([&](auto ic) WFFT_INLINE {
         constexpr int r = decltype(ic)::value;
-        re[r] = (double)in[32 * r];
+        re[r] = (double)in[64 * r];
       });
-      TFHE_STAMP(st, 2);
-      wfft::fwd1024_twisted_real<kPolymulScalar>(re, im, wave_tiles + h * wfft::kHalfBytes, tE, tq, q);
-      TFHE_STAMP(st, 3);
-      static_for<0, 32>([&](auto ic) WFFT_INLINE {
+      wfft64::fwd1024_twisted_real(re, im, tile, tb, lane);
+      static_for<0, 16>([&](auto ic) WFFT_INLINE {
         constexpr int p = decltype(ic)::value;
-        wfft::agpr_put_f64(re[p], park[4 * p + 0], park[4 * p + 1]);
-        wfft::agpr_put_f64(im[p], park[4 * p + 2], park[4 * p + 3]);
+        pre[p] = re[p];
+        pim[p] = im[p];
       });
       constexpr double kScale = 1.0 / 1024.0;                    // a power of two: exact
-      wfft::chunked_for32<8>([&](auto ic) WFFT_INLINE {
+      static_for<0, 16>([&](auto ic) WFFT_INLINE {
         constexpr int r = decltype(ic)::value;
-        re[r] = (double)in[2 * kN + 32 * r] * kScale;
+        re[r] = (double)in[kN + 64 * r] * kScale;
       });
-      // this pair's operands are in registers: start the copy of the next pair's
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (2 * (pair + stride) < B) fetch(pair + stride, lane);
-      TFHE_STAMP(st, 4);
-      wfft::fwd1024_twisted_real<kPolymulScalar>(re, im, wave_tiles + h * wfft::kHalfBytes, tE, tq, q);
-      TFHE_STAMP(st, 5);
+      if (prod + stride < B) fetch(prod + stride, lane);
+      wfft64::fwd1024_twisted_real(re, im, tile, tb, lane);
     }
     __builtin_amdgcn_sched_barrier(0);
     wfft::chunked_for32<4>([&](auto ic) WFFT_INLINE {
       constexpr int p = decltype(ic)::value;
-      const double pr = wfft::agpr_get_f64(park[4 * p + 0], park[4 * p + 1]);
-      const double pi = wfft::agpr_get_f64(park[4 * p + 2], park[4 * p + 3]);
-      const double qr = re[p], qi = im[p];
-      re[p] = pr * qr - pi * qi;
-      im[p] = pr * qi + pi * qr;
+      if constexpr (p < 16) {
+        const double pr = pre[p], pi = pim[p];
+        const double qr = re[p], qi = im[p];
+        re[p] = pr * qr - pi * qi;
+        im[p] = pr * qi + pi * qr;
+      }
     });
     __builtin_amdgcn_sched_barrier(0);
-    TFHE_STAMP(st, 7);
-    const int lane = fresh_lane(), h = lane >> 5, q = lane & 31;
-    // afterwards re = coefficients t < N, im = coefficients N + t of this lane's product,
-    // t = q + 32 r
-    wfft::inv1024_twisted_real<!ACCUMULATE, kPolymulScalar>(
-        re, im, wave_tiles + h * wfft::kHalfBytes, tE, tq, q,
+    const int lane = fresh_lane();
+    // afterwards re = coefficients t < N, im = coefficients N + t of this product, t = lane + 64 r
+    wfft64::inv1024_twisted_real<!ACCUMULATE>(
+        re, im, tile, tb, lane,
         [&](auto rc, double v) WFFT_INLINE { re[decltype(rc)::value] = v; },
         [&](auto rc, double v) WFFT_INLINE { im[decltype(rc)::value] = v; });
-    TFHE_STAMP(st, 9);
-    const int prod = h ? ib : ia;        // one product per half-wave
-    const bool live = h ? has_b : true;
     if (MARGIN) {
       Margin mg;
-      static_for<0, 32>([&](auto ic) WFFT_INLINE {
+      static_for<0, 16>([&](auto ic) WFFT_INLINE {
         constexpr int r = decltype(ic)::value;
         mg.track(re[r]);
-        if (r < 31 || q < 31) mg.track(im[r]);
+        if (r < 15 || lane < 63) mg.track(im[r]);
       });
-      for (int off = 16; off >= 1; off >>= 1) {          // largest value of each half-wave
+      for (int off = 32; off >= 1; off >>= 1) {
         mg.all = fmax(mg.all, __shfl_xor(mg.all, off, 64));
         mg.deciding = fmax(mg.deciding, __shfl_xor(mg.deciding, off, 64));
       }
-      if (live && q == 0) {
+      if (lane == 0) {
         margin[2 * (size_t)prod + 0] = mg.all;
         margin[2 * (size_t)prod + 1] = mg.deciding;
       }
-    } else if (live) {
-      // one base address per lane; the coefficients of a lane are 32 apart
-      if (ACCUMULATE) {
-        int32_t* dst = out + (size_t)prod * kN + q;
-        int32_t old[32];
-        static_for<0, 32>([&](auto ic) WFFT_INLINE { old[decltype(ic)::value] = dst[32 * decltype(ic)::value]; });
-        static_for<0, 32>([&](auto ic) WFFT_INLINE {
-          constexpr int r = decltype(ic)::value;
-          dst[32 * r] = wadd(old[r], wfft::round_sat_i32(re[r]));
-        });
-      } else {
-        int32_t* lo_p = out + (size_t)prod * (2 * kN - 1) + q;
-        int32_t* hi_p = lo_p + kN;
-        static_for<0, 32>([&](auto ic) WFFT_INLINE {
-          constexpr int r = decltype(ic)::value;
-          lo_p[32 * r] = wfft::round_sat_i32(re[r]);
-          if (r < 31 || q < 31) hi_p[32 * r] = wfft::round_sat_i32(im[r]);      // 2N-1 coefficients
-        });
+    } else if (ACCUMULATE) {
+      int32_t* dst = out + (size_t)prod * kN + lane;
+      int32_t old[16];
+      static_for<0, 16>([&](auto ic) WFFT_INLINE { old[decltype(ic)::value] = dst[64 * decltype(ic)::value]; });
+      static_for<0, 16>([&](auto ic) WFFT_INLINE {
+        constexpr int r = decltype(ic)::value;
+        dst[64 * r] = wadd(old[r], wfft::round_sat_i32(re[r]));
+      });
+    } else {
+      int32_t* lo_p = out + (size_t)prod * (2 * kN - 1) + lane;
+      int32_t* hi_p = lo_p + kN;
+      static_for<0, 16>([&](auto ic) WFFT_INLINE {
+        constexpr int r = decltype(ic)::value;
+        lo_p[64 * r] = wfft::round_sat_i32(re[r]);
+        if (r < 15 || lane < 63) hi_p[64 * r] = wfft::round_sat_i32(im[r]);      // 2N-1 coefficients
+      });
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// tfhe_blind_rotate_and_extract / tfhe_blind_rotate with the transforms of wave_fft64.hpp:
+// one wavefront still owns one ciphertext for all n iterations, but a transform now takes the
+// whole wavefront (64 lanes x 16 complex registers) and the two digit polynomials of a level
+// are processed one after the other.  A wavefront then needs half the registers and half the
+// LDS of blind_rotate_kernel, so TWO wavefronts share a SIMD and the LDS round trips,
+// key loads and waits of one hide behind the arithmetic of the other; and both result
+// polynomials live in the same lanes, so the second product of a level needs no exchange.
+//
+// Lane `lane`, register r holds coefficient lane + 64 r of a polynomial.  Per wavefront: the
+// accumulator acc[2][16] in registers; in LDS the exchange tile (which also stages prev + acc
+// for the rotation) and the sample being decomposed (XORed with tt_mask) as lane-private
+// 16-byte granules; the previous accumulator, touched once per iteration, in a workspace in
+// global memory (8 KiB per wavefront slot, L2 resident) as lane-private 16-byte granules:
+// 256 registers and 18 KiB of LDS per wavefront hold nothing more.
+// The key is the one blind_rotate_kernel reads ([n][l][block][32][64], half-wave (h, q),
+// register p_old: value q + 32 br5(p_old) of K_{h,h} / K_{h,1-h}): wave_fft64.hpp's spectrum
+// layout wants value kr + 16 c + 64 br4(p) in lane (kr3 kr2 c1 c0 kr1 kr0), register p, which is
+// q = kr + 16 (c & 1), p_old = p + 16 (c >> 1): a per-lane base address, then the same
+// register stride.
+// ---------------------------------------------------------------------------
+constexpr int kTt64Bytes = 2 * kN * 4;
+static_assert(wfft64::kTileBytes >= 2 * kN * 4, "the tile stages prev + acc of both polynomials");
+static_assert(wfft64::kTileBytes + kTt64Bytes == kWave64Bytes, "one LDS share for both wavefront-per-transform kernels");
+#ifndef TFHE_K64_DEPTH
+#define TFHE_K64_DEPTH 3
+#endif
+
+struct RegisterSink64 {
+  int32_t (&acc)[2][16];
+  template <int U, class RC, class M>
+  __device__ __forceinline__ void add(RC, double v, M& margin) {
+    margin.track(v);
+    acc[U][RC::value] = wadd(acc[U][RC::value], wfft::round_sat_i32(v));
+  }
+};
+
+// One decomposition level of the external product (src/tgsw.rs:229-264, src/tlwe.rs:149-157,
+// src/numerics.rs:138-155): for h = 0, 1 the level-p digits of tt[h] (src/tgsw.rs:299-328),
+// their twisted transform D_h, and the products D_h K_{h,h} -> result polynomial h and
+// D_h K_{h,1-h} -> result polynomial 1 - h, each rounded and saturated on its own before the
+// wrapping add.  bk_level: [2][32][64] complex (block, register, lane of blind_rotate_kernel).
+template <int BGBIT, class M>
+__device__ __forceinline__ void level_product64(int p, const char* tt_lds, const cplx* __restrict__ bk_level,
+                                                int32_t (&acc)[2][16], char* tile, const wfft64::Tables& tb,
+                                                int lane, M& margin) {
+  typedef int int4v __attribute__((ext_vector_type(4)));
+  const int decal = 32 - (p + 1) * BGBIT;
+  const int4v* tt = reinterpret_cast<const int4v*>(tt_lds) + lane;      // granule (h, g) at [(4 h + g) * 64]
+  static_for<0, 2>([&](auto hc) WFFT_INLINE {
+    constexpr int h = decltype(hc)::value;
+    double re[16], im[16], zr[16], zi[16];
+    wfft::wave_lds_fence();
+    static_for<0, 4>([&](auto gc) WFFT_INLINE {
+      constexpr int g = decltype(gc)::value;
+      const int4v t = tt[(4 * h + g) * 64];
+      re[4 * g + 0] = (double)(int32_t)__builtin_amdgcn_sbfe(t.x, decal, BGBIT);
+      re[4 * g + 1] = (double)(int32_t)__builtin_amdgcn_sbfe(t.y, decal, BGBIT);
+      re[4 * g + 2] = (double)(int32_t)__builtin_amdgcn_sbfe(t.z, decal, BGBIT);
+      re[4 * g + 3] = (double)(int32_t)__builtin_amdgcn_sbfe(t.w, decal, BGBIT);
+    });
+    // this lane's spectrum values in the half-wave layout of the key (see the kernel's comment)
+    const int key_lane = (((lane >> 3) & 1) * 16) * 64 + h * 32 + (((lane >> 4) << 2) | (lane & 3)) +
+                         16 * ((lane >> 2) & 1);
+    const cplx* ka = bk_level + key_lane;
+    const cplx* kb = bk_level + 2048 + key_lane;
+    auto load_a = [&](auto ic) WFFT_INLINE { return ka[decltype(ic)::value * 64]; };
+    auto load_b = [&](auto ic) WFFT_INLINE { return kb[decltype(ic)::value * 64]; };
+    wfft64::fwd1024_twisted_real(re, im, tile, tb, lane);
+    {
+      // Z = D_h K_{h,h} into registers of its own: D_h stays where it is for the second product
+      wfft64::Pipe16<4, TFHE_K64_DEPTH, cplx> kp;
+      kp.prologue(load_a);
+      kp.run2(load_a, [&](auto i0, const cplx& k0, auto i1, const cplx& k1) WFFT_INLINE {
+        constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;
+        zr[s0] = re[s0] * k0.x - im[s0] * k0.y;
+        zi[s0] = re[s0] * k0.y + im[s0] * k0.x;
+        zr[s1] = re[s1] * k1.x - im[s1] * k1.y;
+        zi[s1] = re[s1] * k1.y + im[s1] * k1.x;
+      });
+    }
+    RegisterSink64 sink{acc};
+    wfft64::inv1024_twisted_real<false>(
+        zr, zi, tile, tb, lane, [&](auto rc, double v) WFFT_INLINE { sink.template add<h>(rc, v, margin); },
+        [](auto, double) {});
+    {
+      wfft64::Pipe16<4, TFHE_K64_DEPTH, cplx> kp;
+      kp.prologue(load_b);
+      kp.run2(load_b, [&](auto i0, const cplx& k0, auto i1, const cplx& k1) WFFT_INLINE {
+        constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;
+        wfft::cmul2<false>(re[s0], im[s0], k0, re[s1], im[s1], k1);
+      });
+    }
+    wfft64::inv1024_twisted_real<false>(
+        re, im, tile, tb, lane, [&](auto rc, double v) WFFT_INLINE { sink.template add<1 - h>(rc, v, margin); },
+        [](auto, double) {});
+  });
+}
+
+// t = X^abar (prev + acc) - acc for polynomials 0 and 1 (src/bootstrapping.rs:136-146,
+// src/polynomial.rs:281-313) into tt_lds (XORed with mask, see tt_mask; lane-private 16-byte
+// granules), then prev <- acc.  prev_ws: this wavefront's previous accumulator in global memory,
+// as lane-private 16-byte granules ((h, g) at [(4 h + g) * 64 + lane]); have_prev = false stands
+// for the all-zero previous accumulator a blind rotation starts with.  GENERAL as in rotate_diff.
+template <bool GENERAL>
+__device__ __forceinline__ void rotate_diff64(const int32_t (&acc)[2][16], int abar, char* tile, char* tt_lds,
+                                              int32_t* __restrict__ prev_ws, bool have_prev, int lane,
+                                              uint32_t mask) {
+  typedef int int4v __attribute__((ext_vector_type(4)));
+  int32_t* S = reinterpret_cast<int32_t*>(tile);                  // [2][N]: prev + acc
+  int4v* pv = reinterpret_cast<int4v*>(prev_ws) + lane;
+  int32_t v[2][16];
+  if (have_prev) {
+    static_for<0, 8>([&](auto ic) WFFT_INLINE {
+      constexpr int h = decltype(ic)::value >> 2, g = decltype(ic)::value & 3;
+      const int4v x = pv[(4 * h + g) * 64];
+      v[h][4 * g] = x.x; v[h][4 * g + 1] = x.y; v[h][4 * g + 2] = x.z; v[h][4 * g + 3] = x.w;
+    });
+  } else {
+    static_for<0, 32>([&](auto ic) WFFT_INLINE { v[decltype(ic)::value >> 4][decltype(ic)::value & 15] = 0; });
+  }
+  wfft::wave_lds_fence();
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
+    constexpr int h = decltype(ic)::value >> 4, r = decltype(ic)::value & 15;
+    S[h * kN + lane + 64 * r] = wadd(v[h][r], acc[h][r]);
+  });
+  static_for<0, 8>([&](auto ic) WFFT_INLINE {
+    constexpr int h = decltype(ic)::value >> 2, g = decltype(ic)::value & 3;
+    pv[(4 * h + g) * 64] = int4v{acc[h][4 * g], acc[h][4 * g + 1], acc[h][4 * g + 2], acc[h][4 * g + 3]};
+  });
+  wfft::wave_lds_fence();
+  // coefficient n comes from (n - pw) mod N, negated as rotate_diff explains
+  int base, wrap = 0;
+  bool cycle = false;
+  if constexpr (GENERAL) {
+    const MonomialPower mp = monomial_power(abar);
+    base = lane - mp.pw;
+    cycle = mp.cycle;
+  } else {
+    base = lane - abar;
+    wrap = abar > 0 ? base : (abar == -kN ? -(1 << 20) : (1 << 20));
+  }
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
+    constexpr int h = decltype(ic)::value >> 4, r = decltype(ic)::value & 15;
+    v[h][r] = S[h * kN + ((base + 64 * r) & (kN - 1))];
+  });
+  wfft::wave_lds_fence();
+  static_for<0, 32>([&](auto ic) WFFT_INLINE {
+    constexpr int h = decltype(ic)::value >> 4, r = decltype(ic)::value & 15;
+    const bool neg = GENERAL ? ((base < -64 * r) != cycle) : (wrap < -64 * r);
+    const int32_t x = neg ? wneg(v[h][r]) : v[h][r];
+    v[h][r] = (int32_t)((uint32_t)wsub(x, acc[h][r]) ^ mask);
+  });
+  int4v* tt = reinterpret_cast<int4v*>(tt_lds) + lane;
+  static_for<0, 8>([&](auto ic) WFFT_INLINE {
+    constexpr int h = decltype(ic)::value >> 2, g = decltype(ic)::value & 3;
+    tt[(4 * h + g) * 64] = int4v{v[h][4 * g], v[h][4 * g + 1], v[h][4 * g + 2], v[h][4 * g + 3]};
+  });
+}
+
+template <int L, int BGBIT, bool HOOK>
+__global__ __launch_bounds__(64 * kWaves64) void blind_rotate64_kernel(BlindRotateArgs args) {
+  __shared__ __attribute__((aligned(16))) char lds[kLds64Bytes];
+  const wfft64::Tables tb = load_tables64(lds + kWaves64 * kWave64Bytes, args.tables64);
+  const int lane0 = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* tile = lds + wave * kWave64Bytes;
+  char* tt_lds = tile + wfft64::kTileBytes;
+  // persistent workgroups: wavefront slot s takes ciphertexts s, s + slots, ...
+  const int slot = blockIdx.x * kWaves64 + wave;
+  const int slots = gridDim.x * kWaves64;
+  int32_t* prev_ws = args.prev_ws + (size_t)slot * 2 * kN;
+  NoMargin no_margin;
+
+#pragma unroll 1
+  for (int b = slot; b < args.B; b += slots) {
+    int32_t acc[2][16];
+    static_for<0, 32>([&](auto ic) WFFT_INLINE {
+      constexpr int h = decltype(ic)::value >> 4, r = decltype(ic)::value & 15;
+      acc[h][r] = HOOK ? args.acc_io[((size_t)b * 3 + h) * kN + lane0 + 64 * r] : 0;
+    });
+    bool have_prev = false;                                       // prev = 0, bootstrapping.rs:116-117
+
+    const int32_t* bara = args.bara + (size_t)b * args.n;
+    int abar64 = 0;          // the next 64 rotation amounts, one per lane
+#pragma unroll 1
+    for (int i = 0; i < args.n; i++) {
+      if ((i & 63) == 0) abar64 = (i + lane0 < args.n) ? bara[i + lane0] : 0;
+      const int abar = __builtin_amdgcn_readlane(abar64, i & 63);
+      if (abar == 0) continue;                                   // bootstrapping.rs:122-126
+      int lane = lane0;
+      asm volatile("" : "+v"(lane));
+      rotate_diff64<HOOK>(acc, abar, tile, tt_lds, prev_ws, have_prev, lane, tt_mask<L, BGBIT>());   // also prev <- acc
+      have_prev = true;
+      const cplx* bk_i = args.bkfft + (size_t)i * L * 4 * 1024;
+#pragma unroll 1
+      for (int p = 0; p < L; p++)
+        level_product64<BGBIT>(p, tt_lds, bk_i + (size_t)p * 4 * 1024, acc, tile, tb, lane, no_margin);
+    }
+
+    if (HOOK) {
+      static_for<0, 32>([&](auto ic) WFFT_INLINE {
+        constexpr int h = decltype(ic)::value >> 4, r = decltype(ic)::value & 15;
+        args.acc_io[((size_t)b * 3 + h) * kN + lane0 + 64 * r] = acc[h][r];
+      });
+    } else {
+      // extract_lwe, src/tlwe.rs:159-180 (k = 1): a[0] = acc0[0], a[j] = -acc0[N-j].
+      int32_t* oa = args.out_a + (size_t)b * kN;
+      static_for<0, 16>([&](auto ic) WFFT_INLINE {
+        constexpr int r = decltype(ic)::value;
+        const int t = lane0 + 64 * r;
+        if (t == 0) oa[0] = acc[0][r];
+        else oa[kN - t] = wneg(acc[0][r]);
+      });
+      if (lane0 == 0) {
+        const int32_t barb = args.barb[b];                       // bootstrapping.rs:58-96
+        args.out_b[b] = barb >= 0 ? args.mu : wneg(args.mu);
       }
     }
-    TFHE_STAMP(st, 10);
-#ifdef TFHE_STAMPS
-    if (pair + stride >= B / 2 && blockIdx.x == 7 && lane0 == 0 && wave == 1)
-      for (int k = 0; k < 16; k++) g_stamps[k] = st.acc[k];
-#endif
   }
 }
 
@@ -1451,6 +1659,8 @@ int alloc_keys(tfhe_hip_ctx* ctx, const tfhe_hip_params* p) {
   blob_sizes(p, &ctx->bk_bytes, &ctx->ks_bytes, &ctx->ks_rows_bytes);
   HIP_TRY(ctx, hipMalloc((void**)&ctx->bkfft, ctx->bk_bytes));
   HIP_TRY(ctx, hipMalloc((void**)&ctx->ksblob, ctx->ks_bytes));
+  if (!ctx->prev_ws)       // one slot per wavefront of a full blind_rotate64_kernel launch
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->prev_ws, (size_t)ctx->num_cus * kWaves64 * 2 * kN * sizeof(int32_t)));
   return 0;
 }
 
@@ -1541,16 +1751,20 @@ int launch_blind_rotate(tfhe_hip_ctx* ctx, const int32_t* bara, const int32_t* b
                         int32_t* acc_io, int32_t* out_a, int32_t* out_b, size_t B) {
   BlindRotateArgs a;
   a.bara = bara; a.barb = barb; a.bkfft = ctx->bkfft; a.tables = ctx->tables;
+  a.tables64 = ctx->tables64;
+  a.prev_ws = ctx->prev_ws;
   a.acc_io = acc_io; a.out_a = out_a; a.out_b = out_b; a.mu = mu; a.n = ctx->P.n; a.B = (int32_t)B;
   const bool hook = acc_io != nullptr;
   // Batches that cannot give every SIMD its own ciphertext run with one
   // workgroup per ciphertext (2 l wavefronts each, a third of the latency);
   // larger ones with one persistent workgroup per compute unit (160 KiB of LDS
   // each), one ciphertext per wavefront.
-  const bool split = ctx->br_mode == TFHE_HIP_BR_SPLIT ||
-                     (ctx->br_mode == TFHE_HIP_BR_AUTO && B <= 2 * (size_t)ctx->num_cus);
+  int mode = ctx->br_mode;
+  if (mode == TFHE_HIP_BR_AUTO)
+    mode = B <= 2 * (size_t)ctx->num_cus ? TFHE_HIP_BR_SPLIT
+                                         : (ctx->P.l == 2 ? TFHE_HIP_BR_BATCH64 : TFHE_HIP_BR_BATCH);
   ProfileScope prof(ctx, 1);
-  if (split) {
+  if (mode == TFHE_HIP_BR_SPLIT) {
     const dim3 grid((unsigned)B);
     if (ctx->P.l == 2) {
       if (hook) hipLaunchKernelGGL((blind_rotate_split_kernel<2, 10, true, 1>), grid, dim3(256), 0, ctx->stream, a);
@@ -1558,6 +1772,16 @@ int launch_blind_rotate(tfhe_hip_ctx* ctx, const int32_t* bara, const int32_t* b
     } else {
       if (hook) hipLaunchKernelGGL((blind_rotate_split_kernel<3, 7, true, 2>), grid, dim3(192), 0, ctx->stream, a);
       else hipLaunchKernelGGL((blind_rotate_split_kernel<3, 7, false, 2>), grid, dim3(192), 0, ctx->stream, a);
+    }
+  } else if (mode == TFHE_HIP_BR_BATCH64) {
+    const unsigned grid = (unsigned)std::min<size_t>((B + kWaves64 - 1) / kWaves64, (size_t)ctx->num_cus);
+    const dim3 block(64 * kWaves64);
+    if (ctx->P.l == 2) {
+      if (hook) hipLaunchKernelGGL((blind_rotate64_kernel<2, 10, true>), dim3(grid), block, 0, ctx->stream, a);
+      else hipLaunchKernelGGL((blind_rotate64_kernel<2, 10, false>), dim3(grid), block, 0, ctx->stream, a);
+    } else {
+      if (hook) hipLaunchKernelGGL((blind_rotate64_kernel<3, 7, true>), dim3(grid), block, 0, ctx->stream, a);
+      else hipLaunchKernelGGL((blind_rotate64_kernel<3, 7, false>), dim3(grid), block, 0, ctx->stream, a);
     }
   } else {
     const unsigned grid = (unsigned)std::min<size_t>((B + kWavesPerBlock - 1) / kWavesPerBlock,
@@ -1639,6 +1863,30 @@ void make_tables(std::vector<cplx>& t) {
       root(t[2048 + a * 32 + b], (long double)(a * b) / 1024.0L);
       root(t[3072 + a * 32 + b], (long double)(b + 32 * a) / 4096.0L);
     }
+}
+
+// wave_fft64.hpp: T1[kr][lane] = w1024^(lane kr) w4096^lane, then T2[c - 1][ql] = w64^(ql c)
+void make_tables64(std::vector<cplx>& t) {
+  t.resize(wfft64::kT1Entries + wfft64::kT2Entries);
+  const long double two_pi = 6.283185307179586476925286766559L;
+  auto root = [&](cplx& w, long double turns) {
+    w.x = (double)cosl(-two_pi * turns);
+    w.y = (double)sinl(-two_pi * turns);
+  };
+  for (int kr = 0; kr < 16; kr++)
+    for (int lane = 0; lane < 64; lane++)
+      root(t[kr * 64 + lane], (long double)(lane * kr) / 1024.0L + (long double)lane / 4096.0L);
+  for (int c = 1; c < 4; c++)
+    for (int ql = 0; ql < 16; ql++) root(t[wfft64::kT1Entries + (c - 1) * 16 + ql], (long double)(ql * c) / 64.0L);
+}
+
+// (cos, -sin)(2 pi r / 64) for wfft64::g_w64
+void make_w64(double (&w)[32]) {
+  const long double two_pi = 6.283185307179586476925286766559L;
+  for (int r = 0; r < 16; r++) {
+    w[2 * r] = (double)cosl(-two_pi * (long double)r / 64.0L);
+    w[2 * r + 1] = (double)sinl(-two_pi * (long double)r / 64.0L);
+  }
 }
 
 // (cos, -sin)(2 pi r / 128) for wfft::g_w128
@@ -1751,16 +1999,28 @@ int tfhe_hip_create(tfhe_hip_ctx** out, int device) {
   }
   if (hipMalloc((void**)&ctx->tables, t.size() * sizeof(cplx)) != hipSuccess ||
       hipMemcpy(ctx->tables, t.data(), t.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) {
-    delete ctx;
+    tfhe_hip_destroy(ctx);
     return TFHE_HIP_ERR_RUNTIME;
   }
+  std::vector<cplx> t64;
+  make_tables64(t64);
+  double w64[32];
+  make_w64(w64);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(wfft64::g_w64), w64, sizeof(w64)) != hipSuccess ||
+      hipMalloc((void**)&ctx->tables64, t64.size() * sizeof(cplx)) != hipSuccess ||
+      hipMemcpy(ctx->tables64, t64.data(), t64.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) {
+    tfhe_hip_destroy(ctx);
+    return TFHE_HIP_ERR_RUNTIME;
+  }
+
   *out = ctx;
   return 0;
 }
 
 int tfhe_hip_set_blind_rotate_mode(tfhe_hip_ctx* ctx, int mode) {
   if (!ctx) return TFHE_HIP_ERR_ARG;
-  if (mode != TFHE_HIP_BR_AUTO && mode != TFHE_HIP_BR_BATCH && mode != TFHE_HIP_BR_SPLIT)
+  if (mode != TFHE_HIP_BR_AUTO && mode != TFHE_HIP_BR_BATCH && mode != TFHE_HIP_BR_SPLIT &&
+      mode != TFHE_HIP_BR_BATCH64)
     return fail(ctx, TFHE_HIP_ERR_ARG, "unknown blind-rotate mode");
   ctx->br_mode = mode;
   for (tfhe_hip_ctx* s : ctx->shards) s->br_mode = mode;
@@ -1778,6 +2038,8 @@ void tfhe_hip_destroy(tfhe_hip_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   tfhe_detail::release_handles(ctx);
   if (ctx->tables) (void)hipFree(ctx->tables);
+  if (ctx->tables64) (void)hipFree(ctx->tables64);
+  if (ctx->prev_ws) (void)hipFree(ctx->prev_ws);
   if (ctx->bkfft) (void)hipFree(ctx->bkfft);
   if (ctx->ksblob) (void)hipFree(ctx->ksblob);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
@@ -1880,6 +2142,7 @@ int keys_from_device(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, const int
     hipLaunchKernelGGL(bk_fft_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, bk_dev, ctx->tables,
                        ctx->bkfft, (int)count);
     HIP_TRY(ctx, hipGetLastError());
+
   }
   {
     const size_t rows = (size_t)P.n_ks * P.ks_t * 4;
@@ -2170,13 +2433,11 @@ int tfhe_hip_polymul_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32_t* s, 
   if (!d || !s || !out) return fail(ctx, TFHE_HIP_ERR_ARG, "polynomial pointer is NULL");
   if (B > (size_t)INT32_MAX) return fail(ctx, TFHE_HIP_ERR_ARG, "batch too large");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const size_t pairs = (B + 1) / 2;
-  const unsigned grid = (unsigned)std::min<size_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock,
-                                                   (size_t)ctx->num_cus);
+  const unsigned grid64 = (unsigned)std::min<size_t>((B + kWaves64 - 1) / kWaves64, (size_t)ctx->num_cus);
   if (accumulate)
-    hipLaunchKernelGGL((polymul_kernel<true, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (double*)nullptr, (int)B);
+    hipLaunchKernelGGL((polymul64_kernel<true, false>), dim3(grid64), dim3(64 * kWaves64), 0, ctx->stream, d, s, ctx->tables64, out, (double*)nullptr, (int)B);
   else
-    hipLaunchKernelGGL((polymul_kernel<false, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s, ctx->tables, out, (double*)nullptr, (int)B);
+    hipLaunchKernelGGL((polymul64_kernel<false, false>), dim3(grid64), dim3(64 * kWaves64), 0, ctx->stream, d, s, ctx->tables64, out, (double*)nullptr, (int)B);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
@@ -2362,11 +2623,9 @@ int tfhe_hip_polymul_margin_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32
   if (!d || !s || !margin) return fail(ctx, TFHE_HIP_ERR_ARG, "polynomial pointer is NULL");
   if (B > (size_t)INT32_MAX) return fail(ctx, TFHE_HIP_ERR_ARG, "batch too large");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const size_t pairs = (B + 1) / 2;
-  const unsigned grid = (unsigned)std::min<size_t>((pairs + kWavesPerBlock - 1) / kWavesPerBlock,
-                                                   (size_t)ctx->num_cus);
-  hipLaunchKernelGGL((polymul_kernel<false, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, d, s,
-                     ctx->tables, (int32_t*)nullptr, margin, (int)B);
+  const unsigned grid64 = (unsigned)std::min<size_t>((B + kWaves64 - 1) / kWaves64, (size_t)ctx->num_cus);
+  hipLaunchKernelGGL((polymul64_kernel<false, true>), dim3(grid64), dim3(64 * kWaves64), 0, ctx->stream, d, s,
+                       ctx->tables64, (int32_t*)nullptr, margin, (int)B);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }

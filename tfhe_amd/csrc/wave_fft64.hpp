@@ -1,0 +1,371 @@
+// wave_fft64.hpp — f64 FFT machinery in which one WAVEFRONT (64 lanes x 16 complex registers)
+// owns one 1024-point transform, so that a wavefront needs half the registers of the
+// half-wave form in wave_fft.hpp and two wavefronts fit on a SIMD.
+//
+// Element n = lane + 64 r of a sequence lives in lane `lane`, register r.  With
+// n = 64 r + 16 a + ql (a = lane >> 4, ql = lane & 15) and k = kr + 16 c + 64 kq,
+//   w1024^(nk) = w16^(r kr) . w1024^(lane kr) . w4^(a c) . w64^(ql c) . w16^(ql kq),
+// so the 1024-point DFT is
+//   1. a 16-point DFT over the registers                        r  -> kr
+//   2. the twiddle T1[kr][lane] = w1024^(lane kr)               (table in LDS)
+//   3. lane bits (5, 4) <-> register bits (kr3, kr2)            (v_permlane32_swap, v_permlane16_swap:
+//                                                                no LDS traffic, no arithmetic)
+//   4. a 4-point DFT over the registers that now hold a         a  -> c
+//   5. the twiddle T2 = w64^(ql c)                              (three factors per lane)
+//   6. a 16 x 16 transpose inside every row of 16 lanes         (through LDS): registers <-> ql
+//   7. a 16-point DFT over the registers                        ql -> kq
+// and the inverse is the mirror image with conjugated factors.  Afterwards lane
+// (kr3 kr2 | c1 c0 kr1 kr0), register p holds X[kr + 16 c + 64 br4(p)] ("spectrum layout"); the
+// forward transform writes it and the inverse reads it, nothing else depends on it.
+// tests/wave64_model.py is the numpy model of exactly this data movement.
+//
+// Register-index conventions: a LOGICAL index x of a 16-point pass (kr, or (c, kr1 kr0)) lives
+// in physical register br4(x); the registers of a pass's natural side (r, ql) are in order.
+#pragma once
+
+#include "wave_fft.hpp"
+
+namespace wfft64 {
+
+using wfft::cplx;
+using wfft::f64x2;
+using wfft::static_for;
+using wfft::wave_lds_fence;
+
+constexpr int kRowStride = 144;                   // 16 f64 of a tile row + 16 bytes of padding
+constexpr int kTileBytes = 4 * 16 * kRowStride;   // one f64 per (lane, register) of a wavefront: 9216
+constexpr int kT1Entries = 16 * 64;               // T1[kr][lane]
+constexpr int kT2Entries = 3 * 16;                // T2[c - 1][ql]
+constexpr int kTableBytes = (kT1Entries + kT2Entries) * (int)sizeof(cplx);
+
+// (cos, -sin)(2 pi r / 64), r = 0..15: the register part w4096^(64 r) of the twist
+__constant__ double g_w64[32];
+
+__device__ __forceinline__ wfft::const_seg_ptr w64_ptr() {
+  wfft::const_seg_ptr p = (wfft::const_seg_ptr)g_w64;
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
+__host__ __device__ constexpr int br4(int v) {
+  return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3);
+}
+
+// Butterflies of one radix-2 stage of a 16-point pass: b = 0..7 (see wfft::stage_tj / stage_i0).
+template <int HALF>
+__host__ __device__ constexpr int nontrivial_count() {
+  int c = 0;
+  for (int b = 0; b < 8; b++) c += (wfft::stage_tj<HALF>(b) != 0 && wfft::stage_tj<HALF>(b) != 8);
+  return c;
+}
+template <int HALF>
+__host__ __device__ constexpr int nontrivial_butterfly(int k) {
+  int c = 0;
+  for (int b = 0; b < 8; b++)
+    if (wfft::stage_tj<HALF>(b) != 0 && wfft::stage_tj<HALF>(b) != 8) {
+      if (c == k) return b;
+      c++;
+    }
+  return -1;
+}
+
+// Decimation in time, bit-reversed in -> natural out; with VIEW_BR on the bit-reversed register
+// view (natural in -> output k in register br4(k)), as wfft::dit_stage.
+template <int HALF, bool INV, bool VIEW_BR>
+__device__ __forceinline__ void dit_stage(double (&re)[16], double (&im)[16]) {
+  static_for<0, 8>([&](auto ic) WFFT_INLINE {
+    constexpr int b = decltype(ic)::value;
+    constexpr int TJ = wfft::stage_tj<HALF>(b);
+    if constexpr (TJ == 0 || TJ == 8) {
+      constexpr int p0 = wfft::stage_i0<HALF>(b), p1 = p0 + HALF;
+      constexpr int i0 = VIEW_BR ? br4(p0) : p0, i1 = VIEW_BR ? br4(p1) : p1;
+      double tr, ti;
+      wfft::mul_w32<TJ, INV>(re[i1], im[i1], tr, ti);
+      const double ar = re[i0], ai = im[i0];
+      re[i0] = ar + tr;
+      im[i0] = ai + ti;
+      re[i1] = ar - tr;
+      im[i1] = ai - ti;
+    }
+  });
+  static_for<0, nontrivial_count<HALF>() / 2>([&](auto kc) WFFT_INLINE {
+    constexpr int b0 = nontrivial_butterfly<HALF>(2 * decltype(kc)::value);
+    constexpr int b1 = nontrivial_butterfly<HALF>(2 * decltype(kc)::value + 1);
+    constexpr int q0 = wfft::stage_i0<HALF>(b0), q1 = wfft::stage_i0<HALF>(b1);
+    constexpr int x0 = VIEW_BR ? br4(q0) : q0, y0 = VIEW_BR ? br4(q0 + HALF) : q0 + HALF;
+    constexpr int x1 = VIEW_BR ? br4(q1) : q1, y1 = VIEW_BR ? br4(q1 + HALF) : q1 + HALF;
+    constexpr int T0 = wfft::stage_tj<HALF>(b0), T1 = wfft::stage_tj<HALF>(b1);
+    double n0r, n0i, n1r, n1i;
+    wfft::dit_butterfly2(re[x0], im[x0], re[y0], im[y0], wfft::cos32(T0),
+                         INV ? wfft::sin32(T0) : -wfft::sin32(T0), n0r, n0i, re[x1], im[x1], re[y1], im[y1],
+                         wfft::cos32(T1), INV ? wfft::sin32(T1) : -wfft::sin32(T1), n1r, n1i);
+    re[x0] = n0r; im[x0] = n0i; re[x1] = n1r; im[x1] = n1i;
+  });
+}
+
+// Forward 16-point pass: natural in -> output k in register br4(k).
+__device__ __forceinline__ void fwd16(double (&re)[16], double (&im)[16]) {
+  dit_stage<1, false, true>(re, im);
+  dit_stage<2, false, true>(re, im);
+  dit_stage<4, false, true>(re, im);
+  dit_stage<8, false, true>(re, im);
+}
+// Inverse (unnormalised) 16-point pass: input k in register br4(k) -> natural out.
+__device__ __forceinline__ void inv16(double (&re)[16], double (&im)[16]) {
+  dit_stage<1, true, false>(re, im);
+  dit_stage<2, true, false>(re, im);
+  dit_stage<4, true, false>(re, im);
+  dit_stage<8, true, false>(re, im);
+}
+
+// Software-pipelined pass over [0, 16) in groups of G (see wfft::Pipe32).
+template <int G, int D, class T>
+struct Pipe16 {
+  T buf[D + 1][G];
+  template <class LoadF>
+  __device__ __forceinline__ void prologue(LoadF&& load) {
+    static_for<0, D * G>([&](auto ic) WFFT_INLINE {
+      constexpr int i = decltype(ic)::value;
+      buf[i / G][i % G] = load(ic);
+    });
+  }
+  template <class LoadF, class Use2F>
+  __device__ __forceinline__ void run2(LoadF&& load, Use2F&& use2) {
+    static_assert(G % 2 == 0 && 16 % G == 0, "pairs");
+    static_for<0, 16 / G>([&](auto gc) WFFT_INLINE {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (g + D < 16 / G) {
+        static_for<0, G>([&](auto ic) WFFT_INLINE {
+          constexpr int e = decltype(ic)::value;
+          buf[(g + D) % (D + 1)][e] = load(std::integral_constant<int, (g + D) * G + e>{});
+        });
+      }
+      static_for<0, G / 2>([&](auto ic) WFFT_INLINE {
+        constexpr int e = 2 * decltype(ic)::value;
+        use2(std::integral_constant<int, g * G + e>{}, buf[g % (D + 1)][e],
+             std::integral_constant<int, g * G + e + 1>{}, buf[g % (D + 1)][e + 1]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+};
+
+#ifndef WFFT64_TW_GROUP
+#define WFFT64_TW_GROUP 4
+#endif
+
+// ---- step 3: lane bits <-> register bits ---------------------------------------------------
+// v_permlane32_swap_b32 a, b swaps lanes 32..63 of a with lanes 0..31 of b; v_permlane16_swap_b32
+// swaps the odd rows (of 16 lanes) of a with the even rows of b.  Applied to the register pair
+// that differs in one index bit, either exchanges that register-index bit with a lane bit.
+template <bool ROW16>
+__device__ __forceinline__ void swap_f64(double& a, double& b) {
+  unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+  unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+  if constexpr (ROW16) {
+    auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    a = __hiloint2double((int)h[0], (int)l[0]);
+    b = __hiloint2double((int)h[1], (int)l[1]);
+  } else {
+    auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    a = __hiloint2double((int)h[0], (int)l[0]);
+    b = __hiloint2double((int)h[1], (int)l[1]);
+  }
+}
+// logical register bit 3 <-> lane bit 5, logical bit 2 <-> lane bit 4 (its own inverse)
+__device__ __forceinline__ void exchange_lane_bits(double (&re)[16], double (&im)[16]) {
+  static_for<0, 8>([&](auto ic) WFFT_INLINE {
+    constexpr int x = decltype(ic)::value;                 // logical index with bit 3 clear
+    swap_f64<false>(re[br4(x)], re[br4(x | 8)]);
+    swap_f64<false>(im[br4(x)], im[br4(x | 8)]);
+  });
+  static_for<0, 8>([&](auto ic) WFFT_INLINE {
+    constexpr int e = decltype(ic)::value;
+    constexpr int x = (e & 3) | ((e & 4) << 1);            // logical index with bit 2 clear
+    swap_f64<true>(re[br4(x)], re[br4(x | 4)]);
+    swap_f64<true>(im[br4(x)], im[br4(x | 4)]);
+  });
+}
+
+// ---- step 4: 4-point DFT over logical bits (3, 2), in place ---------------------------------
+template <bool INV>
+__device__ __forceinline__ void dft4_high_bits(double (&re)[16], double (&im)[16]) {
+  static_for<0, 4>([&](auto jc) WFFT_INLINE {
+    constexpr int j = decltype(jc)::value;
+    constexpr int p0 = br4(j), p1 = br4(4 + j), p2 = br4(8 + j), p3 = br4(12 + j);
+    const double sr = re[p0] + re[p2], si = im[p0] + im[p2];       // x0 + x2
+    const double dr = re[p0] - re[p2], di = im[p0] - im[p2];       // x0 - x2
+    const double tr = re[p1] + re[p3], ti = im[p1] + im[p3];       // x1 + x3
+    const double ur = re[p1] - re[p3], ui = im[p1] - im[p3];       // x1 - x3
+    re[p0] = sr + tr; im[p0] = si + ti;
+    re[p2] = sr - tr; im[p2] = si - ti;
+    if constexpr (!INV) {                                          // X1 = d - i u, X3 = d + i u
+      re[p1] = dr + ui; im[p1] = di - ur;
+      re[p3] = dr - ui; im[p3] = di + ur;
+    } else {
+      re[p1] = dr - ui; im[p1] = di + ur;
+      re[p3] = dr + ui; im[p3] = di - ur;
+    }
+  });
+}
+
+// ---- step 6: 16 x 16 transpose inside every row of 16 lanes ----------------------------------
+// Row R = lane >> 4 owns 16 tile rows of kRowStride bytes; lane (R, x) stores the f64 of its
+// register with index i at [R][i][x] and then loads row [R][x][0..15].  The padding of 16 bytes
+// per row keeps the 8-byte stores of a row and the 16-byte loads of eight lanes on distinct
+// banks, with plain immediate offsets (no address arithmetic per access).
+struct TileAddr {
+  char* w;          // + i * kRowStride: where this lane stores the register with index i
+  const char* r;    // + 16 g: granule g (elements 2 g, 2 g + 1) of this lane's row
+};
+// One 8-byte store per register.  Written as an instruction of its own (1): the compiler would
+// otherwise fuse two rows into ds_write2_b64, which costs MI355X's LDS more than two ds_write_b64.
+#ifndef WFFT64_ASM_STORE
+#define WFFT64_ASM_STORE 1
+#endif
+template <int ROW>
+__device__ __forceinline__ void tile_store(const TileAddr& t, double x) {
+#if WFFT64_ASM_STORE
+  typedef __attribute__((address_space(3))) char* lds_ptr;
+  const unsigned a = (unsigned)(uintptr_t)(lds_ptr)t.w;
+  asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(a), "v"(x), "n"(ROW * kRowStride) : "memory");
+#else
+  *reinterpret_cast<double*>(t.w + ROW * kRowStride) = x;
+#endif
+}
+__device__ __forceinline__ TileAddr tile_addr(char* tile, int lane) {
+  char* row0 = tile + (lane >> 4) * (16 * kRowStride);
+  return {row0 + (lane & 15) * 8, row0 + (lane & 15) * kRowStride};
+}
+
+// The real, then the imaginary parts go through the tile (a wavefront's LDS operations execute
+// in program order, so no wait separates the trips).  STORE_BR: the register with index i is
+// physical register br4(i) (else i); LOAD_BR likewise for the registers that receive the row.
+template <bool STORE_BR, bool LOAD_BR>
+__device__ __forceinline__ void row_transpose_load(double (&v)[16], const TileAddr& t) {
+  wave_lds_fence();
+  static_for<0, 8>([&](auto gc) WFFT_INLINE {
+    constexpr int g = decltype(gc)::value;
+    const f64x2 w = *reinterpret_cast<const f64x2*>(t.r + 16 * g);
+    v[LOAD_BR ? br4(2 * g) : 2 * g] = w.a;
+    v[LOAD_BR ? br4(2 * g + 1) : 2 * g + 1] = w.b;
+  });
+  wave_lds_fence();
+}
+template <bool STORE_BR, bool LOAD_BR>
+__device__ __forceinline__ void row_transpose(double (&v)[16], const TileAddr& t) {
+  static_for<0, 16>([&](auto ic) WFFT_INLINE {
+    constexpr int i = decltype(ic)::value;
+    tile_store<i>(t, v[STORE_BR ? br4(i) : i]);
+  });
+  row_transpose_load<STORE_BR, LOAD_BR>(v, t);
+}
+
+// Tables in LDS: T1 [16][64] then T2 [3][16] (make_tables64 on the host).
+struct Tables {
+  const cplx* t1;
+  const cplx* t2;
+};
+
+// ---- the twisted transforms of a REAL polynomial (see wave_fft.hpp for the mathematics) ------
+// x[lane + 64 r] in re[r] -> spectrum layout.  The register part w64^r of the twist w4096^n comes
+// from the constant segment (scalar loads), the lane part w4096^lane is folded into T1.
+__device__ __forceinline__ void fwd1024_twisted_real(double (&re)[16], double (&im)[16], char* tile,
+                                                     const Tables& tb, int lane) {
+  static_for<0, 4>([&](auto gc) WFFT_INLINE {
+    wfft::const_seg_ptr g = w64_ptr();
+    static_for<0, 4>([&](auto ic) WFFT_INLINE {
+      constexpr int r = decltype(gc)::value * 4 + decltype(ic)::value;
+      const double c = g[2 * r], s = g[2 * r + 1];
+      im[r] = re[r] * s;
+      re[r] = re[r] * c;
+    });
+  });
+  fwd16(re, im);
+  wave_lds_fence();
+  {
+    Pipe16<WFFT64_TW_GROUP, 1, cplx> pipe;
+    auto load = [&](auto ic) WFFT_INLINE { return tb.t1[br4(decltype(ic)::value) * 64 + lane]; };
+    pipe.prologue(load);
+    pipe.run2(load, [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
+      constexpr int p0 = decltype(i0)::value, p1 = decltype(i1)::value;      // physical: kr = br4(p)
+      wfft::cmul2<false>(re[p0], im[p0], w0, re[p1], im[p1], w1);
+    });
+  }
+  exchange_lane_bits(re, im);
+  dft4_high_bits<false>(re, im);
+  const TileAddr ta = tile_addr(tile, lane);
+  {
+    // T2 = w64^(ql c) on the registers (c, j), c = 1..3; the real parts leave for the tile at once
+    const cplx* t2 = tb.t2 + (lane & 15);
+    const cplx w1 = t2[0], w2 = t2[16], w3 = t2[32];
+    const cplx* wc[3] = {&w1, &w2, &w3};
+    static_for<0, 4>([&](auto jc) WFFT_INLINE {
+      constexpr int j = decltype(jc)::value;
+      tile_store<j>(ta, re[br4(j)]);
+    });
+    static_for<1, 4>([&](auto cc) WFFT_INLINE {
+      constexpr int c = decltype(cc)::value;
+      static_for<0, 2>([&](auto hc) WFFT_INLINE {
+        constexpr int x0 = 4 * c + 2 * decltype(hc)::value, x1 = x0 + 1;
+        wfft::cmul2<false>(re[br4(x0)], im[br4(x0)], *wc[c - 1], re[br4(x1)], im[br4(x1)], *wc[c - 1]);
+        tile_store<x0>(ta, re[br4(x0)]);
+        tile_store<x1>(ta, re[br4(x1)]);
+      });
+    });
+  }
+  row_transpose_load<true, false>(re, ta);
+  row_transpose<true, false>(im, ta);
+  fwd16(re, im);
+}
+
+// Spectrum C (spectrum layout) -> lo(integral_constant<r>, 1024 c[t]) and, when HI,
+// hi(integral_constant<r>, 1024 c[t + 1024]) for t = lane + 64 r.
+template <bool HI, class Lo, class Hi>
+__device__ __forceinline__ void inv1024_twisted_real(double (&re)[16], double (&im)[16], char* tile,
+                                                     const Tables& tb, int lane, Lo&& lo, Hi&& hi) {
+  inv16(re, im);
+  const TileAddr ta = tile_addr(tile, lane);
+  row_transpose<false, true>(re, ta);
+  row_transpose<false, true>(im, ta);
+  {
+    const cplx* t2 = tb.t2 + (lane & 15);
+    const cplx w1 = t2[0], w2 = t2[16], w3 = t2[32];
+    const cplx* wc[3] = {&w1, &w2, &w3};
+    static_for<1, 4>([&](auto cc) WFFT_INLINE {
+      constexpr int c = decltype(cc)::value;
+      static_for<0, 2>([&](auto hc) WFFT_INLINE {
+        constexpr int x0 = 4 * c + 2 * decltype(hc)::value, x1 = x0 + 1;
+        wfft::cmul2<true>(re[br4(x0)], im[br4(x0)], *wc[c - 1], re[br4(x1)], im[br4(x1)], *wc[c - 1]);
+      });
+    });
+  }
+  dft4_high_bits<true>(re, im);
+  exchange_lane_bits(re, im);
+  wave_lds_fence();
+  {
+    Pipe16<WFFT64_TW_GROUP, 1, cplx> pipe;
+    auto load = [&](auto ic) WFFT_INLINE { return tb.t1[br4(decltype(ic)::value) * 64 + lane]; };
+    pipe.prologue(load);
+    pipe.run2(load, [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
+      constexpr int p0 = decltype(i0)::value, p1 = decltype(i1)::value;
+      wfft::cmul2<true>(re[p0], im[p0], w0, re[p1], im[p1], w1);
+    });
+  }
+  inv16(re, im);
+  static_for<0, 4>([&](auto gc) WFFT_INLINE {
+    wfft::const_seg_ptr g = w64_ptr();
+    static_for<0, 4>([&](auto ic) WFFT_INLINE {
+      constexpr int r = decltype(gc)::value * 4 + decltype(ic)::value;
+      const std::integral_constant<int, r> rc;
+      const double c = g[2 * r], s = g[2 * r + 1];
+      const double l = re[r] * c + im[r] * s;          // y conj(w64^r)
+      if constexpr (HI) hi(rc, re[r] * s - im[r] * c);
+      lo(rc, l);
+    });
+  });
+}
+
+}  // namespace wfft64

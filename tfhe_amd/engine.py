@@ -218,10 +218,11 @@ class Engine:
         self._check(self.lib.tfhe_hip_set_stream(
             self.ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
 
-    BR_MODES = {"auto": 0, "batch": 1, "split": 2}
+    BR_MODES = {"auto": 0, "batch": 1, "split": 2, "batch64": 3}
 
     def set_blind_rotate_mode(self, mode):
-        """'batch' = one ciphertext per wavefront, 'split' = one per workgroup, 'auto' by batch size."""
+        """'batch' / 'batch64' = one ciphertext per wavefront with one / two wavefronts per SIMD,
+        'split' = one per workgroup, 'auto' by batch size and parameter set."""
         self._check(self.lib.tfhe_hip_set_blind_rotate_mode(self.ctx, self.BR_MODES[mode]))
 
     def profile_enable(self, on=True):
