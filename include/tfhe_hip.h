@@ -36,6 +36,24 @@ extern "C" {
 
 typedef struct tfhe_hip_ctx tfhe_hip_ctx;
 
+/* Which build of the library this is.
+ * "reference": libtfhe_hip.so, the drop-in for the crate's bootstrapped path; its results are the
+ *   crate's, rule for rule (what this header documents).
+ * "textbook": libtfhe_hip_textbook.so, built from the same sources with -DTFHE_TEXTBOOK: the
+ *   same entry points with the crate's deviations from TFHE corrected, so that bootstrapped
+ *   gates decrypt to their truth tables.  Differences a caller sees: keys have the textbook
+ *   structure (every TGSW row an encryption of zero with k mask polynomials and a body, gadget
+ *   2^(32 - (p+1) bg_bit) on every level; src/tgsw.rs:43-52,118-176, src/tlwe.rs:86,112-134 are
+ *   where the crate departs), bk [n][l][k+1][k+1][N] is [i][level][component][polynomial],
+ *   n_ks must be N k (src/lwe.rs:458-461 builds n rows), products are negacyclic and exact
+ *   (src/numerics.rs:138-155,185-261 computes a saturated plain convolution), rotation amounts
+ *   are in [0, 2N) (src/bootstrapping.rs:50-55), NOR bootstraps with MU = +1/8
+ *   (src/gates.rs:136 uses -1/8, which inverts it).  tfhe_hip_extprod*, tfhe_hip_blind_rotate* (the
+ *   parity hooks of the reference's intermediate functions) are not part of it, and the
+ *   blind-rotate mode is ignored (one mapping).
+ * No counterpart in the reference. */
+const char* tfhe_hip_variant(void);
+
 /* The integers of Parameters / TGswParams / LweKeySwitchKey that the path
  * reads (src/lwe.rs:155-161, src/tgsw.rs:9-36, src/lwe.rs:496-506).
  * Supported: N = 1024, k = 1, l in {2, 3}, bg_bit*l <= 32, ks_base_bit = 2,

@@ -153,6 +153,25 @@ int32_t orc_lwe_phase(int32_t n, const int32_t* a, int32_t b, const int32_t* lwe
 /* src/encryption.rs:60-62 */
 int orc_decrypt(int32_t n, const int32_t* a, int32_t b, const int32_t* lwe_key);
 
+/* ---- the textbook-correct variant (textbook.cpp; checker of libtfhe_hip_textbook.so) ----
+ * The same path with the crate's deviations from TFHE corrected (listed at the top of
+ * textbook.cpp): acc and bk rows have k+1 polynomials (mask, body), products are negacyclic
+ * and exact (wrapping integers), rotation amounts are in [0, 2N), P->n_ks = N k. */
+void orc_tb_decompose(const int32_t* poly, int32_t N, int32_t l, int32_t bg_bit, int32_t* out);
+void orc_tb_extern_product(const orc_params* P, const int32_t* acc, const int32_t* bk_i, int32_t* result);
+void orc_tb_blind_rotate(const orc_params* P, int32_t* acc, const int32_t* bara, const int32_t* bk);
+void orc_tb_bootstrap_noks(const orc_params* P, const int32_t* bk, int32_t mu, const int32_t* a, int32_t b,
+                           int32_t* out_a, int32_t* out_b);
+void orc_tb_bootstrap(const orc_params* P, const int32_t* bk, const int32_t* ks_a, const int32_t* ks_b,
+                      const double* ks_var, int32_t mu, const int32_t* a, int32_t b, int32_t* out_a,
+                      int32_t* out_b, double* out_var);
+int orc_tb_gate(const orc_params* P, int gate, const int32_t* bk, const int32_t* ks_a, const int32_t* ks_b,
+                const double* ks_var, const int32_t* ca_a, int32_t ca_b, const int32_t* cb_a, int32_t cb_b,
+                const int32_t* cc_a, int32_t cc_b, int32_t* out_a, int32_t* out_b, double* out_var);
+/* lwe_key [n]; tlwe_key [k][N]; bk [n][l][k+1][k+1][N]; ks_* with N k rows. */
+void orc_tb_generate_keys(const orc_params* P, uint64_t seed, int32_t* lwe_key, int32_t* tlwe_key, int32_t* bk,
+                          int32_t* ks_a, int32_t* ks_b, double* ks_var);
+
 /* Deterministic fills used by tests and benches. */
 void orc_fill_uniform_i32(uint64_t seed, int32_t* out, size_t count);
 void orc_fill_range_i32(uint64_t seed, int32_t lo, int32_t hi /*exclusive*/, int32_t* out, size_t count);

@@ -52,6 +52,7 @@ pub const BR_SPLIT: c_int = 2;
 pub const BR_BATCH64: c_int = 3;
 
 extern "C" {
+    pub fn tfhe_hip_variant() -> *const c_char;
     pub fn tfhe_hip_create(out: *mut *mut TfheHipCtx, device: c_int) -> c_int;
     pub fn tfhe_hip_create_multi(
         out: *mut *mut TfheHipCtx,

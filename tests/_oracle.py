@@ -25,7 +25,7 @@ class Params(C.Structure):
 
 
 def _build():
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle.cpp", "oracle.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle.cpp", "textbook.cpp", "oracle.h")]
     if (not os.path.exists(LIB_PATH)
             or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(s) for s in srcs)):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
@@ -74,6 +74,16 @@ lib.orc_lwe_phase.restype = C.c_int32
 lib.orc_decrypt.argtypes = [C.c_int32, i32p, C.c_int32, i32p]
 lib.orc_fill_uniform_i32.argtypes = [C.c_uint64, i32p, C.c_size_t]
 lib.orc_fill_range_i32.argtypes = [C.c_uint64, C.c_int32, C.c_int32, i32p, C.c_size_t]
+
+
+lib.orc_tb_decompose.argtypes = [i32p, C.c_int32, C.c_int32, C.c_int32, i32p]
+lib.orc_tb_extern_product.argtypes = [PP, i32p, i32p, i32p]
+lib.orc_tb_blind_rotate.argtypes = [PP, i32p, i32p, i32p]
+lib.orc_tb_bootstrap_noks.argtypes = [PP, i32p, C.c_int32, i32p, C.c_int32, i32p, IP]
+lib.orc_tb_bootstrap.argtypes = [PP, i32p, i32p, i32p, C.c_void_p, C.c_int32, i32p, C.c_int32, i32p, IP, DP]
+lib.orc_tb_gate.argtypes = [PP, C.c_int, i32p, i32p, i32p, C.c_void_p, i32p, C.c_int32, i32p, C.c_int32,
+                            i32p, C.c_int32, i32p, IP, DP]
+lib.orc_tb_generate_keys.argtypes = [PP, C.c_uint64, i32p, i32p, i32p, i32p, i32p, f64p]
 
 
 def _vp(arr):
@@ -285,3 +295,77 @@ def range_i32(seed, lo, hi, shape):
     out = np.empty(shape, dtype=np.int32)
     lib.orc_fill_range_i32(seed, lo, hi, out.reshape(-1), out.size)
     return out
+
+
+# ---- the textbook-correct variant (oracle/textbook.cpp) ------------------------------------------
+
+def tb_params(level=80, n=None, bk_stdev=None):
+    """Parameter shape of Parameters::with(level) for the textbook variant: the key-switch key
+    has N k rows.  n: a shorter LWE dimension for fast tests."""
+    p = params(level)
+    if n is not None:
+        p.n = n
+    p.n_ks = p.N * p.k
+    if bk_stdev is not None:
+        p.bk_stdev = bk_stdev
+    return p
+
+
+def tb_key_shapes(P):
+    base = 1 << P.ks_base_bit
+    return dict(lwe_key=(P.n,), tlwe_key=(P.k, P.N), bk=(P.n, P.l, P.k + 1, P.k + 1, P.N),
+                ks_a=(P.n_ks, P.ks_t, base, P.n), ks_b=(P.n_ks, P.ks_t, base), ks_var=(P.n_ks, P.ks_t, base))
+
+
+def tb_generate_keys(P, seed):
+    k = {name: np.zeros(shape, dtype=np.float64 if name.endswith("var") else np.int32)
+         for name, shape in tb_key_shapes(P).items()}
+    lib.orc_tb_generate_keys(C.byref(P), seed, k["lwe_key"], k["tlwe_key"].reshape(-1), k["bk"].reshape(-1),
+                             k["ks_a"].reshape(-1), k["ks_b"].reshape(-1), k["ks_var"].reshape(-1))
+    return k
+
+
+def tb_decompose(poly, l, bg_bit):
+    poly = np.ascontiguousarray(poly, dtype=np.int32)
+    out = np.empty((l, len(poly)), dtype=np.int32)
+    lib.orc_tb_decompose(poly, len(poly), l, bg_bit, out.reshape(-1))
+    return out
+
+
+def tb_extern_product(P, acc, bk_i):
+    acc = np.ascontiguousarray(acc, dtype=np.int32)
+    out = np.empty_like(acc)
+    lib.orc_tb_extern_product(C.byref(P), acc.reshape(-1), np.ascontiguousarray(bk_i).reshape(-1), out.reshape(-1))
+    return out
+
+
+def tb_blind_rotate(P, acc, bara, bk):
+    acc = np.array(acc, dtype=np.int32)
+    lib.orc_tb_blind_rotate(C.byref(P), acc.reshape(-1), np.ascontiguousarray(bara, dtype=np.int32),
+                            np.ascontiguousarray(bk).reshape(-1))
+    return acc
+
+
+def tb_bootstrap_noks(P, bk, mu, a, b):
+    out = np.empty(P.N * P.k, dtype=np.int32)
+    ob = C.c_int32(0)
+    lib.orc_tb_bootstrap_noks(C.byref(P), np.ascontiguousarray(bk).reshape(-1), mu,
+                              np.ascontiguousarray(a, dtype=np.int32), int(b), out, C.byref(ob))
+    return out, ob.value
+
+
+def tb_gate(P, gate, keys, ca, cb, cc=None):
+    """Samples are (a, b); returns (a, b, variance of the key switch)."""
+    if cc is None:
+        cc = (np.zeros(P.n, dtype=np.int32), 0)
+    out = np.empty(P.n, dtype=np.int32)
+    ob = C.c_int32(0)
+    var = C.c_double(0.0)
+    rc = lib.orc_tb_gate(C.byref(P), GATE_ID[gate], np.ascontiguousarray(keys["bk"]).reshape(-1),
+                         np.ascontiguousarray(keys["ks_a"]).reshape(-1),
+                         np.ascontiguousarray(keys["ks_b"]).reshape(-1), _vp(keys.get("ks_var")),
+                         np.ascontiguousarray(ca[0], dtype=np.int32), int(ca[1]),
+                         np.ascontiguousarray(cb[0], dtype=np.int32), int(cb[1]),
+                         np.ascontiguousarray(cc[0], dtype=np.int32), int(cc[1]), out, C.byref(ob), C.byref(var))
+    assert rc == 0
+    return out, ob.value, var.value

@@ -10,9 +10,11 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # TFHE_HIP_LIB overrides the library path (kernel experiments).
 LIB_PATH = os.environ.get("TFHE_HIP_LIB") or os.path.join(HERE, "libtfhe_hip.so")
+# the textbook-correct variant, a library of its own with the same entry points
+TEXTBOOK_LIB_PATH = os.path.join(HERE, "libtfhe_hip_textbook.so")
 
 SYMBOLS = [
-    "tfhe_hip_create", "tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_key_transport", "tfhe_hip_set_stream", "tfhe_hip_set_blind_rotate_mode",
+    "tfhe_hip_variant", "tfhe_hip_create", "tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_key_transport", "tfhe_hip_set_stream", "tfhe_hip_set_blind_rotate_mode",
     "tfhe_hip_circuit_add", "tfhe_hip_circuit_add_dev",
     "tfhe_hip_synchronize", "tfhe_hip_load_keys", "tfhe_hip_key_blob_sizes",
     "tfhe_hip_export_keys_dev", "tfhe_hip_import_keys_dev", "tfhe_hip_bootstrap",
@@ -30,7 +32,7 @@ SYMBOLS = [
     "tfhe_hip_generate_keys", "tfhe_hip_keygen_stream",
     "tfhe_hip_circuit_compare", "tfhe_hip_circuit_compare_dev", "tfhe_hip_circuit_eq", "tfhe_hip_circuit_eq_dev",
 ]
-NO_INT_RESULT = ("tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_key_transport", "tfhe_hip_samples_free", "tfhe_hip_samples_count")
+NO_INT_RESULT = ("tfhe_hip_variant", "tfhe_hip_destroy", "tfhe_hip_last_error", "tfhe_hip_key_transport", "tfhe_hip_samples_free", "tfhe_hip_samples_count")
 
 
 class Params(C.Structure):
@@ -39,18 +41,21 @@ class Params(C.Structure):
                 ("n", "N", "k", "l", "bg_bit", "ks_t", "ks_base_bit", "n_ks")]
 
 
-def load():
-    if not os.path.exists(LIB_PATH):
+def load(variant="reference"):
+    path = {"reference": LIB_PATH, "textbook": TEXTBOOK_LIB_PATH}[variant]
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: the HIP library must be built (there is no CPU fallback)")
+            f"{path} is missing: the HIP library must be built (there is no CPU fallback)")
     try:
         # If torch is going to be used in this process it must own the HIP runtime.
         import torch  # noqa: F401
     except Exception:
         pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     vp, i32p, f64p, sz = C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t
     PP = C.POINTER(Params)
+    lib.tfhe_hip_variant.argtypes = []
+    lib.tfhe_hip_variant.restype = C.c_char_p
     lib.tfhe_hip_create.argtypes = [C.POINTER(vp), C.c_int]
     lib.tfhe_hip_destroy.argtypes = [vp]
     lib.tfhe_hip_destroy.restype = None
@@ -113,4 +118,6 @@ def load():
         fn = getattr(lib, name)
         if name not in NO_INT_RESULT:
             fn.restype = C.c_int
+    if "TFHE_HIP_LIB" not in os.environ and lib.tfhe_hip_variant().decode() != variant:
+        raise ImportError(f"{path} is not the {variant} build")
     return lib

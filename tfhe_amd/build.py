@@ -23,6 +23,10 @@ UNITS = [
 ]
 SRC = UNITS[0][0]
 OUT = os.path.join(HERE, "libtfhe_hip.so")
+# The textbook-correct variant: the kernel unit compiled with -DTFHE_TEXTBOOK, linked with the
+# same host layer into a library of its own (never a run-time switch inside libtfhe_hip.so).
+TEXTBOOK_OBJ = os.path.join(CSRC, "tfhe_hip_textbook.o")
+TEXTBOOK_OUT = os.path.join(HERE, "libtfhe_hip_textbook.so")
 
 
 def _stale(target, deps):
@@ -44,6 +48,13 @@ def build_library(force=False, verbose=False):
     if relink or _stale(OUT, objs):
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
                               + ["-ldl", "-lpthread"])
+    src, _, deps, flags = UNITS[0]
+    if force or _stale(TEXTBOOK_OBJ, [src] + deps + COMMON_DEPS):
+        subprocess.check_call([hipcc, "-O3", "-std=c++17", "-fPIC", "-c", "-DTFHE_TEXTBOOK"] + flags
+                              + ["-o", TEXTBOOK_OBJ, src])
+    if force or _stale(TEXTBOOK_OUT, [TEXTBOOK_OBJ, objs[1]]):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", TEXTBOOK_OUT,
+                               TEXTBOOK_OBJ, objs[1], "-ldl", "-lpthread"])
     return OUT
 
 

@@ -107,8 +107,14 @@ __device__ __forceinline__ int32_t wadd(int32_t a, int32_t b) { return (int32_t)
 __device__ __forceinline__ int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
 __device__ __forceinline__ int32_t wneg(int32_t a) { return (int32_t)(0u - (uint32_t)a); }
 
+#ifndef TFHE_TEXTBOOK
 // decode_message(x, 2N), src/numerics.rs:126-130 with N = 1024.
 __device__ __forceinline__ int32_t mod_switch_2n(int32_t x) { return wadd(x, 1 << 20) >> 21; }
+#else
+// Textbook build: the nearest multiple of 1/2N as an UNSIGNED residue in [0, 2N)
+// (src/numerics.rs:126-130 shifts arithmetically and yields [-N, N)).
+__device__ __forceinline__ int32_t mod_switch_2n(int32_t x) { return (int32_t)(((uint32_t)x + (1u << 20)) >> 21); }
+#endif
 
 // The power of mul_by_monomial reduced as src/polynomial.rs:289-291 does it:
 // cycle = (power / N).modulo(2) == 1, pw = power % N (truncating division and
@@ -1127,6 +1133,189 @@ __global__ __launch_bounds__(64 * kWaves64) void blind_rotate64_kernel(BlindRota
   }
 }
 
+#ifdef TFHE_TEXTBOOK
+// ===========================================================================
+// The textbook-correct variant (libtfhe_hip_textbook.so, built with -DTFHE_TEXTBOOK; the
+// library without that flag contains none of this).  The same path with the crate's
+// deviations from TFHE corrected where the crate has them:
+//   * gadget h[p] = 2^(32 - (p+1) bg_bit) on every level, decomposition offset over all levels
+//     (src/tgsw.rs:43-52), every TGSW row a TLWE encryption of zero (src/tgsw.rs:118-127),
+//     message * h[p] on polynomial j of row (p, j) (src/tgsw.rs:129-167);
+//   * TLWE samples of k mask polynomials and a body, products negacyclic mod X^N + 1 and not
+//     saturated (src/tlwe.rs:86,112-134, src/numerics.rs:138-155,185-261);
+//   * the external product decomposes and updates the body too (src/tgsw.rs:229-297);
+//   * acc <- acc + bk_i [.] (X^abar acc - acc) with abar, bbar in [0, 2N)
+//     (src/bootstrapping.rs:50-55,109-146);
+//   * key switch over N k coefficients (src/lwe.rs:458-461): n_ks = N k in the parameters;
+//   * NOR bootstraps with MU = +1/8 (src/gates.rs:136 uses -1/8, which inverts the gate).
+// The products of one external product are not rounded one by one any more, so they are summed
+// in the frequency domain: (k+1) l forward and k+1 inverse transforms per iteration instead of
+// (k+1) l and (k+1)^2 l.  The negacyclic product is the low half of the linear convolution
+// minus the high half, both of which the twisted inverse transform delivers.  Exactness: the
+// summed coefficients stay below 2^50, where the transforms' error is of the order 0.05, far
+// from the 0.5 that would move a rounding; the result is then reduced modulo 2^32.
+//
+// One wavefront per ciphertext, one wavefront per SIMD (wave_fft64.hpp transforms).
+// Key: [n][l][j][u][16][64] complex, the spectrum (scaled by 1/1024) of polynomial u of row
+// (level, component j) of bk[i].
+// ===========================================================================
+constexpr int kTbWaves = 4;
+constexpr int kTbLdsBytes = kTbWaves * wfft64::kTileBytes + wfft64::kTableBytes;
+
+template <int L, int BGBIT>
+constexpr uint32_t tb_offset() {           // sum over the levels of Bg/2 * 2^(32 - (p+1) bg_bit)
+  uint32_t o = 0;
+  for (int p = 0; p < L; p++) o += (1u << (BGBIT - 1)) << (32 - (p + 1) * BGBIT);
+  return o;
+}
+template <int L, int BGBIT>
+constexpr uint32_t tb_field_tops() {       // the top bit of every digit field: field - Bg/2 = sign-extended (field ^ top)
+  uint32_t m = 0;
+  for (int p = 0; p < L; p++) m |= 1u << (31 - p * BGBIT);
+  return m;
+}
+
+// x mod 2^32 of the integer nearest to x (ties to even), exact for |x| < 2^51
+__device__ __forceinline__ int32_t round_wrap_i32(double x) {
+  return (int32_t)(uint32_t)(unsigned long long)__double_as_longlong(x + 6755399441055744.0);
+}
+
+template <int L, int BGBIT>
+__global__ __launch_bounds__(64 * kTbWaves, 1) void blind_rotate_textbook_kernel(BlindRotateArgs args) {
+  __shared__ __attribute__((aligned(16))) char lds[kTbLdsBytes];
+  const wfft64::Tables tb = load_tables64(lds + kTbWaves * wfft64::kTileBytes, args.tables64);
+  const int lane0 = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* tile = lds + wave * wfft64::kTileBytes;
+  const int slot = blockIdx.x * kTbWaves + wave, slots = gridDim.x * kTbWaves;
+
+#pragma unroll 1
+  for (int b = slot; b < args.B; b += slots) {
+    int32_t acc[2][16];                      // polynomial 0: mask, 1: body; coefficient lane + 64 r
+    {
+      // acc = trivial(X^(2N - barb) [mu]*N), src/bootstrapping.rs:89-96
+      const int w0 = (2 * kN - args.barb[b]) & (2 * kN - 1);
+      const bool flip = w0 >= kN;
+      const int w = flip ? w0 - kN : w0;
+      static_for<0, 16>([&](auto ic) WFFT_INLINE {
+        constexpr int r = decltype(ic)::value;
+        acc[0][r] = 0;
+        acc[1][r] = ((lane0 + 64 * r < w) != flip) ? wneg(args.mu) : args.mu;
+      });
+    }
+    const int32_t* bara = args.bara + (size_t)b * args.n;
+    int abar64 = 0;
+#pragma unroll 1
+    for (int i = 0; i < args.n; i++) {
+      if ((i & 63) == 0) abar64 = (i + lane0 < args.n) ? bara[i + lane0] : 0;
+      const int abar = __builtin_amdgcn_readlane(abar64, i & 63);
+      if (abar == 0) continue;
+      int lane = lane0;
+      asm volatile("" : "+v"(lane));
+      // t = X^abar acc - acc, offset added, field tops flipped (digit p is then a sign-extended field)
+      int32_t tt[2][16];
+      {
+        int32_t* S = reinterpret_cast<int32_t*>(tile);
+        wfft::wave_lds_fence();
+        static_for<0, 32>([&](auto ic) WFFT_INLINE {
+          constexpr int h = decltype(ic)::value >> 4, r = decltype(ic)::value & 15;
+          S[h * kN + lane + 64 * r] = acc[h][r];
+        });
+        wfft::wave_lds_fence();
+        const bool flip = abar >= kN;
+        const int w = flip ? abar - kN : abar;
+        static_for<0, 32>([&](auto ic) WFFT_INLINE {
+          constexpr int h = decltype(ic)::value >> 4, r = decltype(ic)::value & 15;
+          tt[h][r] = S[h * kN + ((lane + 64 * r - w) & (kN - 1))];
+        });
+        wfft::wave_lds_fence();
+        static_for<0, 32>([&](auto ic) WFFT_INLINE {
+          constexpr int h = decltype(ic)::value >> 4, r = decltype(ic)::value & 15;
+          const bool neg = (lane + 64 * r < w) != flip;
+          const int32_t x = neg ? wneg(tt[h][r]) : tt[h][r];
+          tt[h][r] = (int32_t)(((uint32_t)wsub(x, acc[h][r]) + tb_offset<L, BGBIT>()) ^ tb_field_tops<L, BGBIT>());
+        });
+      }
+      // spectra of the two result polynomials, summed over the (k+1) l rows
+      double ur[2][16], ui[2][16];
+      static_for<0, 32>([&](auto ic) WFFT_INLINE {
+        ur[decltype(ic)::value >> 4][decltype(ic)::value & 15] = 0.0;
+        ui[decltype(ic)::value >> 4][decltype(ic)::value & 15] = 0.0;
+      });
+      const cplx* bk_i = args.bkfft + (size_t)i * L * 4 * 1024 + lane;
+      static_for<0, 2 * L>([&](auto rc) WFFT_INLINE {
+        constexpr int p = decltype(rc)::value >> 1, j = decltype(rc)::value & 1;
+        constexpr int decal = 32 - (p + 1) * BGBIT;
+        double re[16], im[16];
+        static_for<0, 16>([&](auto ic) WFFT_INLINE {
+          constexpr int r = decltype(ic)::value;
+          re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(tt[j][r], decal, BGBIT);
+        });
+        wfft64::fwd1024_twisted_real(re, im, tile, tb, lane);
+        static_for<0, 2>([&](auto uc) WFFT_INLINE {
+          constexpr int u = decltype(uc)::value;
+          const cplx* kp = bk_i + ((p * 2 + j) * 2 + u) * 1024;
+          static_for<0, 16>([&](auto ic) WFFT_INLINE {
+            constexpr int s = decltype(ic)::value;
+            const cplx kv = kp[s * 64];
+            ur[u][s] += re[s] * kv.x - im[s] * kv.y;
+            ui[u][s] += re[s] * kv.y + im[s] * kv.x;
+          });
+        });
+      });
+      static_for<0, 2>([&](auto uc) WFFT_INLINE {
+        constexpr int u = decltype(uc)::value;
+        double lo_v[16];
+        wfft64::inv1024_twisted_real<true>(
+            ur[u], ui[u], tile, tb, lane, [&](auto rc, double v) WFFT_INLINE { lo_v[decltype(rc)::value] = v; },
+            [&](auto rc, double v) WFFT_INLINE {
+              // negacyclic product: low half minus high half; the untwist hands hi before lo
+              constexpr int r = decltype(rc)::value;
+              ui[u][r] = v;
+            });
+        static_for<0, 16>([&](auto ic) WFFT_INLINE {
+          constexpr int r = decltype(ic)::value;
+          acc[u][r] = wadd(acc[u][r], round_wrap_i32(lo_v[r] - ui[u][r]));
+        });
+      });
+    }
+    // extract_lwe, src/tlwe.rs:159-180 (k = 1): a[0] = acc0[0], a[j] = -acc0[N-j], b = body[0]
+    int32_t* oa = args.out_a + (size_t)b * kN;
+    static_for<0, 16>([&](auto ic) WFFT_INLINE {
+      constexpr int r = decltype(ic)::value;
+      const int t = lane0 + 64 * r;
+      if (t == 0) oa[0] = acc[0][r];
+      else oa[kN - t] = wneg(acc[0][r]);
+    });
+    if (lane0 == 0) args.out_b[b] = acc[1][0];
+  }
+}
+
+// One-time transform of the bootstrapping key: wavefront s = ((i l + p) 2 + j) 2 + u writes the
+// spectrum of polynomial u of row (p, j) of bk[i] (flat input [i][p][j][u][N]), scaled by 1/1024.
+__global__ __launch_bounds__(64 * kTbWaves, 1) void bk_fft_textbook_kernel(const int32_t* __restrict__ bk,
+                                                                            const cplx* __restrict__ tables64,
+                                                                            cplx* __restrict__ bkfft, int count) {
+  __shared__ __attribute__((aligned(16))) char lds[kTbLdsBytes];
+  const wfft64::Tables tb = load_tables64(lds + kTbWaves * wfft64::kTileBytes, tables64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = blockIdx.x * kTbWaves + wave;
+  if (s >= count) return;
+  const int32_t* p0 = bk + (size_t)s * kN + lane;
+  double re[16], im[16];
+  static_for<0, 16>([&](auto ic) WFFT_INLINE { re[decltype(ic)::value] = (double)p0[64 * decltype(ic)::value]; });
+  wfft64::fwd1024_twisted_real(re, im, lds + wave * wfft64::kTileBytes, tb, lane);
+  cplx* dst = bkfft + (size_t)s * 1024 + lane;
+  static_for<0, 16>([&](auto ic) WFFT_INLINE {
+    constexpr int p = decltype(ic)::value;
+    cplx v;
+    v.x = re[p] * (1.0 / 1024.0);
+    v.y = im[p] * (1.0 / 1024.0);
+    dst[p * 64] = v;
+  });
+}
+#endif  // TFHE_TEXTBOOK
+
 // Gate prologue + mod switch: x = C + wa*ca + wb*cb (wrapping, src/gates.rs,
 // src/lwe.rs:47-136), then bara/barb = decode_message(x, 2N)
 // (src/bootstrapping.rs:50-55).
@@ -1600,6 +1789,44 @@ __global__ __launch_bounds__(256) void keygen_bk_kernel(ChaChaKey key, int l, do
   }
 }
 
+
+#ifdef TFHE_TEXTBOOK
+// Textbook build: bk[i] = TGSW encryption of lwe_key[i] with EVERY row a TLWE encryption of zero
+// (src/tgsw.rs:118-127 fills row 0 only) under the TLWE key: uniform mask a, body
+// b = e + a (x) s mod X^N + 1 (src/tlwe.rs:112-134 multiplies the key with zeros), and the
+// gadget lwe_key[i] * 2^(32 - (p+1) bg_bit) on coefficient 0 of polynomial j of row (p, j)
+// (src/tgsw.rs:43-48,129-167 use h = [l, 0, ..] and add it to every polynomial).  One
+// workgroup per row; layout of tfhe_hip_load_keys, [n][l][2][2][N].
+__global__ __launch_bounds__(256) void keygen_bk_textbook_kernel(ChaChaKey key, int l, int bg_bit, double alpha,
+                                                                 const int32_t* __restrict__ lwe_key,
+                                                                 const int32_t* __restrict__ tlwe_key,
+                                                                 int32_t* __restrict__ bk) {
+  __shared__ int32_t a_s[kN];
+  __shared__ int32_t s_s[kN];
+  const int row = blockIdx.x;                              // (i l + p) 2 + j
+  const int j = row & 1, p = (row >> 1) % l, i = (row >> 1) / l;
+  int32_t* out = bk + (size_t)row * 2 * kN;
+  for (int b0 = threadIdx.x; b0 < kN / 16; b0 += blockDim.x) {
+    uint32_t blk[16];
+    chacha20_block(key, (uint32_t)b0, kRngBkMask, (uint64_t)row, blk);
+    for (int e = 0; e < 16; e++) a_s[b0 * 16 + e] = (int32_t)blk[e];
+  }
+  for (int x = threadIdx.x; x < kN; x += blockDim.x) s_s[x] = tlwe_key[x];
+  __syncthreads();
+  const int32_t gadget = (int32_t)((uint32_t)lwe_key[i] << (32 - (p + 1) * bg_bit));
+  for (int x = threadIdx.x; x < kN; x += blockDim.x) {
+    uint32_t blk[16];
+    chacha20_block(key, (uint32_t)x, kRngBkNoise, (uint64_t)row, blk);
+    uint32_t body = (uint32_t)f64_to_torus32(alpha * normal_from_words(blk));
+    for (int v = 0; v < kN; v++)
+      if (s_s[v]) body += (x >= v) ? (uint32_t)a_s[x - v] : 0u - (uint32_t)a_s[x - v + kN];
+    const int32_t g0 = x == 0 ? gadget : 0;
+    out[x] = wadd(a_s[x], j == 0 ? g0 : 0);
+    out[kN + x] = wadd((int32_t)body, j == 1 ? g0 : 0);
+  }
+}
+#endif
+
 }  // namespace
 
 // Scratch of tfhe_hip_gate_dev_noalloc, the entry point that allocates nothing:
@@ -1703,7 +1930,13 @@ bool gate_weights(int gate, Weights* w) {
     case TFHE_HIP_AND:   *w = {+1, +1, m8, e8}; return true;   // :64-80
     case TFHE_HIP_XOR:   *w = {+2, +2, e4, e8}; return true;   // :83-99
     case TFHE_HIP_XNOR:  *w = {-2, -2, m4, e8}; return true;   // :102-119
+#ifndef TFHE_TEXTBOOK
     case TFHE_HIP_NOR:   *w = {-1, -1, m8, m8}; return true;   // :127-143
+#else
+    // :136 bootstraps NOR with MU = -1/8, which inverts its output; the textbook build uses
+    // +1/8 like every other gate
+    case TFHE_HIP_NOR:   *w = {-1, -1, m8, e8}; return true;
+#endif
     case TFHE_HIP_ANDNY: *w = {-1, +1, m8, e8}; return true;   // :147-162
     case TFHE_HIP_ANDYN: *w = {+1, -1, m8, e8}; return true;   // :166-182
     case TFHE_HIP_ORNY:  *w = {-1, +1, e8, e8}; return true;   // :186-202
@@ -1755,6 +1988,20 @@ int launch_blind_rotate(tfhe_hip_ctx* ctx, const int32_t* bara, const int32_t* b
   a.prev_ws = ctx->prev_ws;
   a.acc_io = acc_io; a.out_a = out_a; a.out_b = out_b; a.mu = mu; a.n = ctx->P.n; a.B = (int32_t)B;
   const bool hook = acc_io != nullptr;
+#ifdef TFHE_TEXTBOOK
+  {
+    // the textbook build has one mapping: one ciphertext per wavefront, one wavefront per SIMD
+    if (hook) return fail(ctx, TFHE_HIP_ERR_ARG, "the blind-rotate hook is not part of the textbook build");
+    ProfileScope prof(ctx, 1);
+    const unsigned grid = (unsigned)std::min<size_t>((B + kTbWaves - 1) / kTbWaves, (size_t)ctx->num_cus);
+    if (ctx->P.l == 2)
+      hipLaunchKernelGGL((blind_rotate_textbook_kernel<2, 10>), dim3(grid), dim3(64 * kTbWaves), 0, ctx->stream, a);
+    else
+      hipLaunchKernelGGL((blind_rotate_textbook_kernel<3, 7>), dim3(grid), dim3(64 * kTbWaves), 0, ctx->stream, a);
+    HIP_TRY(ctx, hipGetLastError());
+    return 0;
+  }
+#endif
   // Batches that cannot give every SIMD its own ciphertext run with one
   // workgroup per ciphertext (2 l wavefronts each, a third of the latency);
   // larger ones with one persistent workgroup per compute unit (160 KiB of LDS
@@ -2057,6 +2304,14 @@ void tfhe_hip_destroy(tfhe_hip_ctx* ctx) {
 
 const char* tfhe_hip_last_error(tfhe_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
+const char* tfhe_hip_variant(void) {
+#ifdef TFHE_TEXTBOOK
+  return "textbook";
+#else
+  return "reference";
+#endif
+}
+
 int tfhe_hip_set_stream(tfhe_hip_ctx* ctx, void* hip_stream) {
   if (!ctx) return TFHE_HIP_ERR_ARG;
   if (!ctx->shards.empty())
@@ -2137,10 +2392,16 @@ int keys_from_device(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, const int
   if (int rc = alloc_keys(ctx, params)) return rc;
   const tfhe_hip_params& P = ctx->P;
   {
+#ifdef TFHE_TEXTBOOK
+    const size_t count = (size_t)P.n * P.l * 4;            // (i, level, component, polynomial)
+    hipLaunchKernelGGL(bk_fft_textbook_kernel, dim3((unsigned)((count + kTbWaves - 1) / kTbWaves)),
+                       dim3(64 * kTbWaves), 0, ctx->stream, bk_dev, ctx->tables64, ctx->bkfft, (int)count);
+#else
     const size_t count = (size_t)P.n * P.l * 2;            // (i, row, col) triples
     const unsigned grid = (unsigned)((count + kWavesPerBlock - 1) / kWavesPerBlock);
     hipLaunchKernelGGL(bk_fft_kernel, dim3(grid), dim3(kBlock), 0, ctx->stream, bk_dev, ctx->tables,
                        ctx->bkfft, (int)count);
+#endif
     HIP_TRY(ctx, hipGetLastError());
 
   }
@@ -2272,8 +2533,13 @@ int tfhe_hip_generate_keys(tfhe_hip_ctx* ctx, const tfhe_hip_params* params, dou
                        (const double*)dnoise.p, (const double*)(partial + noise_blocks), (int32_t*)da.p,
                        (int32_t*)db.p, (double*)dv.p);
     HIP_TRY(c, hipGetLastError());
+#ifdef TFHE_TEXTBOOK
+    hipLaunchKernelGGL(keygen_bk_textbook_kernel, dim3((unsigned)(P.n * P.l * 2)), dim3(256), 0, c->stream, key, P.l,
+                       P.bg_bit, bk_stdev, (const int32_t*)k_lwe, (const int32_t*)k_tlwe, (int32_t*)dbk.p);
+#else
     hipLaunchKernelGGL(keygen_bk_kernel, dim3((unsigned)P.n * 2), dim3(256), 0, c->stream, key, P.l, bk_stdev,
                        (const int32_t*)k_lwe, (int32_t*)dbk.p);
+#endif
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(lwe_key, k_lwe, (size_t)P.n * 4, hipMemcpyDeviceToHost, c->stream));
     if (tlwe_key) HIP_TRY(c, hipMemcpyAsync(tlwe_key, k_tlwe, (size_t)tlwe_count * 4, hipMemcpyDeviceToHost, c->stream));
@@ -2633,6 +2899,9 @@ int tfhe_hip_polymul_margin_dev(tfhe_hip_ctx* ctx, const int32_t* d, const int32
 int tfhe_hip_extprod_dev(tfhe_hip_ctx* ctx, const int32_t* t, int bk_index, int32_t* out,
                          double* margin, size_t B) {
   if (int rc = need_keys(ctx)) return rc;
+#ifdef TFHE_TEXTBOOK
+  return fail(ctx, TFHE_HIP_ERR_ARG, "the external-product hook is not part of the textbook build");
+#endif
   if (B == 0) return 0;
   if (!t || !out) return fail(ctx, TFHE_HIP_ERR_ARG, "sample pointer is NULL");
   if (bk_index < 0 || bk_index >= ctx->P.n) return fail(ctx, TFHE_HIP_ERR_ARG, "bk_index out of range");

@@ -83,8 +83,11 @@ class Samples:
 
 
 class Engine:
-    def __init__(self, device=0):
-        self.lib = _lib.load()
+    def __init__(self, device=0, variant="reference"):
+        """variant: "reference" (libtfhe_hip.so, the crate's results) or "textbook"
+        (libtfhe_hip_textbook.so, the corrected scheme; same entry points)."""
+        self.variant = variant
+        self.lib = _lib.load(variant)
         self.ctx = C.c_void_p()
         if isinstance(device, (list, tuple)):
             devs = (C.c_int * len(device))(*device)
