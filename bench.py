@@ -14,12 +14,19 @@ uniform), so no stage degenerates to zeros; the kernels are data independent.
 --workload nand (default) is the headline metric; its line also carries the
 blind-rotate roofline (live HIP-event durations; traffic from the committed
 counter pass), p50 single-gate latency, a check of one timed output against the
-CPU oracle, the same measurements on the crate's default parameters (Bit128,
-"bit128" block, --no-bit128 skips it) and the CPU baseline (the restated
-reference algorithm on every CPU this job may use).  add32 times the level-batched
-ripple-carry adder (circuits::add on 32-bit operands, 160 gates per instance,
---batch instances per GPU per step); polymul times isolated polynomial products
-(--batch products per step).  Each prints its own single JSON line.
+CPU oracle, the CPU baseline (the restated reference algorithm on every CPU this
+job may use) and, on one GPU, four more blocks, each with its own check against
+the oracle and a flag that skips it:
+  "bit128"   the same batch on the crate's default parameters       (--no-bit128)
+  "polymul"  65 536 isolated polynomial products                    (--no-polymul)
+  "add32"    4 096 level-batched 32-bit ripple-carry additions      (--no-add32)
+  "textbook" the same NAND batch on libtfhe_hip_textbook.so, the textbook-correct
+             variant, with keys it generates itself                 (--no-textbook)
+--workload add32 / polymul time those workloads alone (--batch instances or
+products per step) and print their own single JSON line.
+--single-process --devices 0,1,..: one process drives the listed GPUs through
+tfhe_hip_create_multi and the host-pointer entry points (what a single-threaded caller
+of the crate's API would use) instead of one process per GPU.
 
 For N > 1 launch with torch.distributed.run (one rank per GPU); rank 0 builds
 the keys, their FFT-domain form is broadcast once over RCCL, and every rank
@@ -98,7 +105,7 @@ def measured_traffic(level, batch):
     CDNA4 guide prescribes; tools/collect_profiles.py writes the file).  Counters cannot be
     read inside the timed run, so this is a profiled value: only valid for the workload it was
     collected on, otherwise null."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json",):
         path = os.path.join(ROOT, "profiles", name)
         if level != 80 or batch != 16384 or not os.path.exists(path):
             continue
@@ -282,6 +289,145 @@ def side_workload(args):
         dist.destroy_process_group()
 
 
+def polymul_block(eng, torch, dev, level, B=65536, steps=300, warmup=100):
+    """BASELINE config 2: B isolated products; a sample of them against the exact oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as orc
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    half = 512 if level == 80 else 64
+    d = torch.randint(-half, half, (B, 1024), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
+    s_ = torch.randint(-2**31, 2**31, (B, 1024), dtype=torch.int64, device=dev, generator=g).to(torch.int32)
+    out = torch.empty((B, 2047), dtype=torch.int32, device=dev)
+    for _ in range(warmup):
+        eng.polymul_dev(d, s_, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.polymul_dev(d, s_, out)
+    torch.cuda.synchronize()
+    value = B * steps / (time.perf_counter() - t0)
+    ok = True
+    for i in (0, B // 3, B - 1):
+        want, _ = orc.poly_multiplier(d[i].cpu().numpy(), s_[i].cpu().numpy(), orc.MUL_EXACT)
+        ok = ok and bool((out[i].cpu().numpy() == want).all())
+    flop = 3 * FLOP_FFT + FLOP_POINTWISE
+    return {"metric": "isolated polynomial products/sec (poly_multiplier)", "value": value, "unit": "products/s",
+            "config": f"{B} independent products of a digit polynomial (|d| < {half}) with a uniform Torus32 "
+                      f"polynomial, N = 1024, full 2047-coefficient result",
+            "roofline": {"bound": "fp64_valu", "kernel": "polymul64_kernel", "achieved": value * flop / 1e12,
+                         "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": value * flop / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                         "hbm_GBps_algorithmic": value * (2 * 4096 + 2047 * 4) / 1e9},
+            "output_check": {"products": [0, B // 3, B - 1], "matches_oracle": ok}}
+
+
+def add32_block(eng, torch, dev, level, K, count=4096, bits=32):
+    """BASELINE config 5: `count` instances of circuits::add on `bits`-bit operands, one step;
+    the two lowest sum bits of one instance against the same gates composed on the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as orc
+    n = LEVELS[level]["n"]
+    g = torch.Generator(device=dev)
+    g.manual_seed(4322)
+
+    def rnd(shape):
+        return torch.randint(-2**31, 2**31, shape, dtype=torch.int64, device=dev, generator=g).to(torch.int32)
+
+    a_a, a_b, b_a, b_b = rnd((bits, count, n)), rnd((bits, count)), rnd((bits, count, n)), rnd((bits, count))
+    s_a = torch.empty((bits, count, n), dtype=torch.int32, device=dev)
+    s_b = torch.empty((bits, count), dtype=torch.int32, device=dev)
+    c_a = torch.empty((count, n), dtype=torch.int32, device=dev)
+    c_b = torch.empty((count,), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.circuit_add_dev(a_a, a_b, b_a, b_b, s_a, s_b, c_a, c_b)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    # full_adder of bits 0 and 1 of one instance (src/circuits/circuits.rs:83-97) on the oracle
+    P = orc.params(level)
+    Ko = {k: np.ascontiguousarray(v) for k, v in K.items()}
+    c = count // 2
+    smp = lambda ta, tb, i: (ta[i, c].cpu().numpy(), int(tb[i, c]), 0.0)
+    gate = lambda name, x, y: orc.gate(P, name, Ko, x, y, None, orc.MUL_FFT)
+    carry = (np.zeros(n, np.int32), -(1 << 29), 0.0)                       # constant(false)
+    ok = True
+    for i in range(2):
+        x, y = smp(a_a, a_b, i), smp(b_a, b_b, i)
+        axb = gate("xor", x, y)
+        want = gate("xor", axb, carry)
+        ok = ok and bool((s_a[i, c].cpu().numpy() == want[0]).all() and int(s_b[i, c]) == want[1])
+        if i == 0:
+            carry = gate("or", gate("and", carry, axb), gate("and", x, y))
+    gates = 5 * bits * count
+    return {"metric": "bootstrapped gates/sec inside level-batched ripple-carry adders", "value": gates / elapsed,
+            "unit": "gates/s", "additions_per_sec": count / elapsed, "seconds": elapsed,
+            "config": f"circuits::add, {count} instances of {bits}-bit operands in one call ({5 * bits} bootstrapped "
+                      f"gates each, {2 * bits + 1} dependency levels), Bit{level}",
+            "output_check": {"instance": c, "sum_bits": [0, 1], "matches_oracle": ok}}
+
+
+def textbook_block(torch, dev, level, B, steps):
+    """The same NAND batch on libtfhe_hip_textbook.so (the textbook-correct variant: negacyclic
+    products summed in the frequency domain, all TGSW rows encrypted, N-row key switch), with keys
+    from its own tfhe_hip_generate_keys and fresh encryptions as inputs: gates/s, the blind-rotate
+    roofline on the same algorithmic convention ((k+1) l forward, (k+1) inverse transforms and
+    (k+1)^2 l pointwise products per iteration), every output of a sample decrypted and one
+    gate compared with the exact oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as orc
+    import tfhe_amd
+    eng = tfhe_amd.Engine(dev.index, variant="textbook")
+    try:
+        eng.use_torch_stream()
+        lv = LEVELS[level]
+        P = orc.tb_params(level, bk_stdev=2.0 ** -25 if level == 128 else None)
+        hp = tfhe_amd.make_params(P.n, P.N, P.k, P.l, P.bg_bit, P.ks_t, P.ks_base_bit, P.n_ks)
+        K = eng.generate_keys(hp, P.ks_stdev, P.bk_stdev, bytes(range(32)))
+        # 64 fresh encryptions, tiled over the batch
+        bits = [((i >> 1) & 1, i & 1) for i in range(64)]
+        ca = [orc.encrypt(P, K["lwe_key"], x, 100 + i) for i, (x, _) in enumerate(bits)]
+        cb = [orc.encrypt(P, K["lwe_key"], y, 200 + i) for i, (_, y) in enumerate(bits)]
+        rep = (B + 63) // 64
+        tile = lambda cs, k: torch.from_numpy(np.stack([c[k] for c in cs])).to(dev).repeat((rep,) + (1,) * (k == 0))[:B].contiguous()
+        ca_a, cb_a = tile(ca, 0), tile(cb, 0)
+        ca_b = torch.tensor([c[1] for c in ca], dtype=torch.int32, device=dev).repeat(rep)[:B].contiguous()
+        cb_b = torch.tensor([c[1] for c in cb], dtype=torch.int32, device=dev).repeat(rep)[:B].contiguous()
+        out_a = torch.empty((B, P.n), dtype=torch.int32, device=dev)
+        out_b = torch.empty((B,), dtype=torch.int32, device=dev)
+        eng.gate_dev("nand", ca_a, ca_b, cb_a, cb_b, out_a, out_b)
+        torch.cuda.synchronize()
+        eng.profile_enable(True)
+        eng.profile_read()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.gate_dev("nand", ca_a, ca_b, cb_a, cb_b, out_a, out_b)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        prof = eng.profile_read()
+        br_ms = prof["blind_rotate"][0] / max(prof["blind_rotate"][1], 1)
+        flop = (2 * lv["l"] * FLOP_FFT + 2 * FLOP_FFT + 4 * lv["l"] * FLOP_POINTWISE) * lv["n"] * B
+        oa, ob = out_a[:64].cpu().numpy(), out_b[:64].cpu().numpy()
+        decrypted = all(orc.decrypt(oa[i], ob[i], K["lwe_key"]) == (not (x and y)) for i, (x, y) in enumerate(bits))
+        Ko = {k: np.ascontiguousarray(v) for k, v in K.items()}
+        wa, wb, _ = orc.tb_gate(P, "nand", Ko, ca[3][:2], cb[3][:2])
+        return {"metric": "bootstrapped NAND gates/sec, textbook-correct variant (libtfhe_hip_textbook.so)",
+                "value": B * steps / elapsed, "unit": "gates/s",
+                "config": f"{B} NAND gates per step, Bit{level} shape, keys from tfhe_hip_generate_keys, inputs "
+                          f"fresh encryptions; not the reference's algorithm (see tfhe_hip_variant in the header)",
+                "kernels_ms_per_launch": {"blind_rotate": br_ms,
+                                          "keyswitch": prof["keyswitch"][0] / max(prof["keyswitch"][1], 1)},
+                "roofline": {"bound": "fp64_valu", "kernel": "blind_rotate_textbook_kernel",
+                             "achieved": flop / (br_ms / 1e3) / 1e12 if br_ms else 0.0,
+                             "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": flop / (br_ms / 1e3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if br_ms else 0.0,
+                             "flop_per_launch": flop},
+                "output_check": {"decrypts_to_nand_truth_table": bool(decrypted), "samples": 64,
+                                 "matches_oracle": bool((oa[3] == wa).all() and int(ob[3]) == wb)}}
+    finally:
+        eng.close()
+
+
 def time_nand(eng, torch, dist, dev, world, rank, level, K, B, steps, warmup, check=True, chunk=None,
               total=None):
     """Times `steps` batches of B NAND gates on the loaded keys (each batch in launches of at
@@ -324,8 +470,14 @@ def time_nand(eng, torch, dist, dev, world, rank, level, K, B, steps, warmup, ch
     elapsed = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile_enable(False)
+    per_rank = [B * steps / elapsed]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+        cdev = "cpu" if dist.get_backend() == "gloo" else dev
+        mine = torch.tensor([B * steps / elapsed], dtype=torch.float64, device=cdev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(x.item()) for x in every]
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     br_ms, br_cnt = prof["blind_rotate"]
@@ -338,7 +490,10 @@ def time_nand(eng, torch, dist, dev, world, rank, level, K, B, steps, warmup, ch
     res = {
         "value": (total if total is not None else B * world) * steps / elapsed,
         "ms_per_step": elapsed / steps * 1e3,
-        "roofline": {"bound": "fp64_valu", "kernel": "blind_rotate_kernel",
+        "per_rank_value": per_rank,
+        "roofline": {"bound": "fp64_valu",
+                     # the throughput form the library's AUTO mode picks for this parameter set
+                     "kernel": "blind_rotate64_kernel" if lv["l"] == 2 else "blind_rotate_kernel",
                      "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
                      "measured_fma_stream_peak": FP64_MEASURED_FMA_STREAM_TFLOPS,
@@ -380,6 +535,59 @@ def latency(eng, torch, tensors, K_params_n):
     return p50_dev, p50_host
 
 
+def single_process(args):
+    """One process, many GPUs: tfhe_hip_create_multi over --devices, keys loaded once and
+    replicated by the library (RCCL broadcast or peer copies), every step one host-pointer
+    tfhe_hip_gate call of B gates PER DEVICE that the library splits contiguously and runs at
+    the same time.  Reports the aggregate rate (host staging included: this path hands over host
+    buffers) and, measured in the same process, the rate of the first device alone."""
+    import tfhe_amd
+    devices = [int(x) for x in (args.devices or ",".join(str(i) for i in range(args.gpus))).split(",")]
+    lv = LEVELS[args.level]
+    params = tfhe_amd.make_params(lv["n"], l=lv["l"], bg_bit=lv["bg_bit"])
+    K = synthetic_keys(args.level, 0xC0FFEE + 3)
+    rng = np.random.default_rng(99)
+
+    def run(devs):
+        eng = tfhe_amd.Engine(devs if len(devs) > 1 else devs[0])
+        try:
+            eng.load_keys(params, K["bk"], K["ks_a"], K["ks_b"], K["ks_var"])
+            B = args.batch * len(devs)
+            u = lambda shape: rng.integers(-2**31, 2**31, size=shape, dtype=np.int64).astype(np.int32)
+            ca, cb = (u((B, lv["n"])), u((B,))), (u((B, lv["n"])), u((B,)))
+            for _ in range(args.warmup):
+                out = eng.gate("nand", ca, cb)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out = eng.gate("nand", ca, cb)
+            elapsed = time.perf_counter() - t0
+            transport = eng.key_transport() if len(devs) > 1 else "none"
+            return B * args.steps / elapsed, elapsed / args.steps * 1e3, transport, (ca, cb, out)
+        finally:
+            eng.close()
+
+    value, ms, transport, (ca, cb, out) = run(devices)
+    single = run(devices[:1])[0] if len(devices) > 1 else value
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as orc
+    P = orc.params(args.level)
+    i = out[1].size - 1                                              # a gate of the last device's shard
+    wa, wb, _ = orc.gate(P, "nand", {k: np.ascontiguousarray(v) for k, v in K.items()},
+                         (ca[0][i], ca[1][i], 0.0), (cb[0][i], cb[1][i], 0.0), None, orc.MUL_FFT)
+    res = {"metric": "bootstrapped NAND gates/sec (node, default params)", "value": value, "unit": "gates/s",
+           "n_gpus": len(devices), "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"one process, tfhe_hip_create_multi over devices {devices}: {args.batch} NAND gates "
+                                  f"per device per step through the host-pointer entry point (PCIe staging "
+                                  f"included), Bit{args.level}, synthetic keys replicated by the library",
+                      "batch_per_gpu": args.batch, "security_level": args.level, "key_transport": transport,
+                      "parallelism": "one host thread per device inside the library, batch split contiguously"},
+           "single_device_value": single,
+           "output_check": {"gate_index": int(i), "matches_oracle": bool((out[0][i] == wa).all() and int(out[1][i]) == wb)},
+           "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(args.level)}
+    print(json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -391,6 +599,12 @@ def main():
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--no-bit128", action="store_true",
                     help="skip the Bit128 block that the default Bit80 run adds")
+    ap.add_argument("--no-polymul", action="store_true", help="skip the isolated-product block")
+    ap.add_argument("--no-add32", action="store_true", help="skip the 32-bit adder block")
+    ap.add_argument("--no-textbook", action="store_true", help="skip the textbook-variant block")
+    ap.add_argument("--single-process", action="store_true",
+                    help="one process drives every GPU of --devices through tfhe_hip_create_multi")
+    ap.add_argument("--devices", default=None, help="comma-separated GPU ordinals for --single-process")
     ap.add_argument("--total-gates", type=int, default=None,
                     help="strong scaling: this many gates per step over ALL ranks (contiguous shards, "
                          "launches of --batch gates); BASELINE config 4 is --total-gates 1048576")
@@ -405,6 +619,8 @@ def main():
     args.warmup = dwarm if args.warmup is None else args.warmup
     if args.workload != "nand":
         return side_workload(args)
+    if args.single_process:
+        return single_process(args)
 
     import torch
     import torch.distributed as dist
@@ -458,6 +674,21 @@ def main():
             bit128["unit"] = "gates/s"
             bit128["config"] = "same batch on Bit128 (n=630, N=1024, k=1, l=3, Bg=2^7, ks t=8 base=4)"
 
+    # BASELINE configs 2 and 5 and the textbook-correct variant beside the headline (one GPU only)
+    blocks = {}
+    if world == 1 and not args.total_gates:
+        if not args.no_polymul:
+            blocks["polymul"] = polymul_block(eng, torch, dev, args.level)
+            progress(f"polymul block: {blocks['polymul']['value'] / 1e6:.1f} M products/s")
+        if not args.no_add32:
+            if bit128 is not None:
+                K = load(args.level)                       # the Bit128 block replaced the keys
+            blocks["add32"] = add32_block(eng, torch, dev, args.level, K)
+            progress(f"add32 block: {blocks['add32']['value']:.0f} gates/s")
+        if not args.no_textbook:
+            blocks["textbook"] = textbook_block(torch, dev, args.level, B, 2)
+            progress(f"textbook block: {blocks['textbook']['value']:.0f} gates/s")
+
     if rank == 0:
         res = {
             "metric": "bootstrapped NAND gates/sec (node, default params)",
@@ -480,10 +711,11 @@ def main():
             "output_check": main_res.get("output_check"),
             "bit128": bit128,
         }
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(args.level)
-        else:
-            res["cpu_baseline"] = None
+        res.update(blocks)
+        if world > 1:
+            res["per_rank_value"] = main_res["per_rank_value"]
+        # rank 0's host cores, also for N > 1 (the other ranks wait at the barrier below)
+        res["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.level)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

@@ -50,7 +50,8 @@ def build_library(force=False, verbose=False):
                               + ["-ldl", "-lpthread"])
     src, _, deps, flags = UNITS[0]
     if force or _stale(TEXTBOOK_OBJ, [src] + deps + COMMON_DEPS):
-        subprocess.check_call([hipcc, "-O3", "-std=c++17", "-fPIC", "-c", "-DTFHE_TEXTBOOK"] + flags
+        # key pipeline one group deep: its two result spectra leave the textbook kernel few registers
+        subprocess.check_call([hipcc, "-O3", "-std=c++17", "-fPIC", "-c", "-DTFHE_TEXTBOOK", "-DTFHE_K64_DEPTH=1"] + flags
                               + ["-o", TEXTBOOK_OBJ, src])
     if force or _stale(TEXTBOOK_OUT, [TEXTBOOK_OBJ, objs[1]]):
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", TEXTBOOK_OUT,

@@ -1155,13 +1155,10 @@ __global__ __launch_bounds__(64 * kWaves64) void blind_rotate64_kernel(BlindRota
 // summed coefficients stay below 2^50, where the transforms' error is of the order 0.05, far
 // from the 0.5 that would move a rounding; the result is then reduced modulo 2^32.
 //
-// One wavefront per ciphertext, one wavefront per SIMD (wave_fft64.hpp transforms).
+// One wavefront per ciphertext (wave_fft64.hpp transforms).
 // Key: [n][l][j][u][16][64] complex, the spectrum (scaled by 1/1024) of polynomial u of row
 // (level, component j) of bk[i].
 // ===========================================================================
-constexpr int kTbWaves = 4;
-constexpr int kTbLdsBytes = kTbWaves * wfft64::kTileBytes + wfft64::kTableBytes;
-
 template <int L, int BGBIT>
 constexpr uint32_t tb_offset() {           // sum over the levels of Bg/2 * 2^(32 - (p+1) bg_bit)
   uint32_t o = 0;
@@ -1180,27 +1177,41 @@ __device__ __forceinline__ int32_t round_wrap_i32(double x) {
   return (int32_t)(uint32_t)(unsigned long long)__double_as_longlong(x + 6755399441055744.0);
 }
 
+// Two wavefronts per SIMD, as blind_rotate64_kernel (same LDS share: exchange tile + the
+// sample being decomposed as lane-private granules).  The two result spectra take 128 of a
+// wavefront's 256 registers, so the accumulator itself (touched at the start and at the end of
+// an iteration only) lives in the per-wavefront workspace in global memory, as lane-private
+// 16-byte granules ((h, g) at [(4 h + g) * 64 + lane]).
+typedef int tb_int4 __attribute__((ext_vector_type(4)));
+
 template <int L, int BGBIT>
-__global__ __launch_bounds__(64 * kTbWaves, 1) void blind_rotate_textbook_kernel(BlindRotateArgs args) {
-  __shared__ __attribute__((aligned(16))) char lds[kTbLdsBytes];
-  const wfft64::Tables tb = load_tables64(lds + kTbWaves * wfft64::kTileBytes, args.tables64);
+__global__ __launch_bounds__(64 * kWaves64) void blind_rotate_textbook_kernel(BlindRotateArgs args) {
+  __shared__ __attribute__((aligned(16))) char lds[kLds64Bytes];
+  const wfft64::Tables tb = load_tables64(lds + kWaves64 * kWave64Bytes, args.tables64);
   const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* tile = lds + wave * wfft64::kTileBytes;
-  const int slot = blockIdx.x * kTbWaves + wave, slots = gridDim.x * kTbWaves;
+  char* tile = lds + wave * kWave64Bytes;
+  char* tt_lds = tile + wfft64::kTileBytes;
+  const int slot = blockIdx.x * kWaves64 + wave, slots = gridDim.x * kWaves64;
+  volatile tb_int4* acc_ws = reinterpret_cast<volatile tb_int4*>(args.prev_ws + (size_t)slot * 2 * kN) + lane0;
 
 #pragma unroll 1
   for (int b = slot; b < args.B; b += slots) {
-    int32_t acc[2][16];                      // polynomial 0: mask, 1: body; coefficient lane + 64 r
     {
-      // acc = trivial(X^(2N - barb) [mu]*N), src/bootstrapping.rs:89-96
+      // acc = trivial(X^(2N - barb) [mu]*N), src/bootstrapping.rs:89-96: polynomial 0 (mask) = 0,
+      // polynomial 1 (body) = the rotated test vector
       const int w0 = (2 * kN - args.barb[b]) & (2 * kN - 1);
       const bool flip = w0 >= kN;
       const int w = flip ? w0 - kN : w0;
-      static_for<0, 16>([&](auto ic) WFFT_INLINE {
-        constexpr int r = decltype(ic)::value;
-        acc[0][r] = 0;
-        acc[1][r] = ((lane0 + 64 * r < w) != flip) ? wneg(args.mu) : args.mu;
+      static_for<0, 4>([&](auto gc) WFFT_INLINE {
+        constexpr int g = decltype(gc)::value;
+        acc_ws[g * 64] = tb_int4{0, 0, 0, 0};
+        tb_int4 v;
+        v.x = ((lane0 + 64 * (4 * g + 0) < w) != flip) ? wneg(args.mu) : args.mu;
+        v.y = ((lane0 + 64 * (4 * g + 1) < w) != flip) ? wneg(args.mu) : args.mu;
+        v.z = ((lane0 + 64 * (4 * g + 2) < w) != flip) ? wneg(args.mu) : args.mu;
+        v.w = ((lane0 + 64 * (4 * g + 3) < w) != flip) ? wneg(args.mu) : args.mu;
+        acc_ws[(4 + g) * 64] = v;
       });
     }
     const int32_t* bara = args.bara + (size_t)b * args.n;
@@ -1212,9 +1223,15 @@ __global__ __launch_bounds__(64 * kTbWaves, 1) void blind_rotate_textbook_kernel
       if (abar == 0) continue;
       int lane = lane0;
       asm volatile("" : "+v"(lane));
-      // t = X^abar acc - acc, offset added, field tops flipped (digit p is then a sign-extended field)
-      int32_t tt[2][16];
+      // t = X^abar acc - acc with the decomposition offset added and the top bit of every digit
+      // field flipped (digit p is then a sign-extended bit field), to LDS
       {
+        int32_t acc[2][16], v[2][16];
+        static_for<0, 8>([&](auto ic) WFFT_INLINE {
+          constexpr int h = decltype(ic)::value >> 2, g = decltype(ic)::value & 3;
+          const tb_int4 x = acc_ws[(4 * h + g) * 64];
+          acc[h][4 * g] = x.x; acc[h][4 * g + 1] = x.y; acc[h][4 * g + 2] = x.z; acc[h][4 * g + 3] = x.w;
+        });
         int32_t* S = reinterpret_cast<int32_t*>(tile);
         wfft::wave_lds_fence();
         static_for<0, 32>([&](auto ic) WFFT_INLINE {
@@ -1226,14 +1243,19 @@ __global__ __launch_bounds__(64 * kTbWaves, 1) void blind_rotate_textbook_kernel
         const int w = flip ? abar - kN : abar;
         static_for<0, 32>([&](auto ic) WFFT_INLINE {
           constexpr int h = decltype(ic)::value >> 4, r = decltype(ic)::value & 15;
-          tt[h][r] = S[h * kN + ((lane + 64 * r - w) & (kN - 1))];
+          v[h][r] = S[h * kN + ((lane + 64 * r - w) & (kN - 1))];
         });
         wfft::wave_lds_fence();
         static_for<0, 32>([&](auto ic) WFFT_INLINE {
           constexpr int h = decltype(ic)::value >> 4, r = decltype(ic)::value & 15;
           const bool neg = (lane + 64 * r < w) != flip;
-          const int32_t x = neg ? wneg(tt[h][r]) : tt[h][r];
-          tt[h][r] = (int32_t)(((uint32_t)wsub(x, acc[h][r]) + tb_offset<L, BGBIT>()) ^ tb_field_tops<L, BGBIT>());
+          const int32_t x = neg ? wneg(v[h][r]) : v[h][r];
+          v[h][r] = (int32_t)(((uint32_t)wsub(x, acc[h][r]) + tb_offset<L, BGBIT>()) ^ tb_field_tops<L, BGBIT>());
+        });
+        tb_int4* tt = reinterpret_cast<tb_int4*>(tt_lds) + lane;
+        static_for<0, 8>([&](auto ic) WFFT_INLINE {
+          constexpr int h = decltype(ic)::value >> 2, g = decltype(ic)::value & 3;
+          tt[(4 * h + g) * 64] = tb_int4{v[h][4 * g], v[h][4 * g + 1], v[h][4 * g + 2], v[h][4 * g + 3]};
         });
       }
       // spectra of the two result polynomials, summed over the (k+1) l rows
@@ -1243,68 +1265,89 @@ __global__ __launch_bounds__(64 * kTbWaves, 1) void blind_rotate_textbook_kernel
         ui[decltype(ic)::value >> 4][decltype(ic)::value & 15] = 0.0;
       });
       const cplx* bk_i = args.bkfft + (size_t)i * L * 4 * 1024 + lane;
-      static_for<0, 2 * L>([&](auto rc) WFFT_INLINE {
-        constexpr int p = decltype(rc)::value >> 1, j = decltype(rc)::value & 1;
-        constexpr int decal = 32 - (p + 1) * BGBIT;
+#pragma unroll 1
+      for (int row = 0; row < 2 * L; row++) {            // row = 2 p + j: level p, component j
+        const int decal = 32 - ((row >> 1) + 1) * BGBIT;
+        const tb_int4* tt = reinterpret_cast<const tb_int4*>(tt_lds) + lane + (row & 1) * 4 * 64;
         double re[16], im[16];
-        static_for<0, 16>([&](auto ic) WFFT_INLINE {
-          constexpr int r = decltype(ic)::value;
-          re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(tt[j][r], decal, BGBIT);
+        wfft::wave_lds_fence();
+        static_for<0, 4>([&](auto gc) WFFT_INLINE {
+          constexpr int g = decltype(gc)::value;
+          const tb_int4 t = tt[g * 64];
+          re[4 * g + 0] = (double)(int32_t)__builtin_amdgcn_sbfe(t.x, decal, BGBIT);
+          re[4 * g + 1] = (double)(int32_t)__builtin_amdgcn_sbfe(t.y, decal, BGBIT);
+          re[4 * g + 2] = (double)(int32_t)__builtin_amdgcn_sbfe(t.z, decal, BGBIT);
+          re[4 * g + 3] = (double)(int32_t)__builtin_amdgcn_sbfe(t.w, decal, BGBIT);
         });
         wfft64::fwd1024_twisted_real(re, im, tile, tb, lane);
+        const cplx* krow = bk_i + (size_t)row * 2 * 1024;
         static_for<0, 2>([&](auto uc) WFFT_INLINE {
           constexpr int u = decltype(uc)::value;
-          const cplx* kp = bk_i + ((p * 2 + j) * 2 + u) * 1024;
-          static_for<0, 16>([&](auto ic) WFFT_INLINE {
-            constexpr int s = decltype(ic)::value;
-            const cplx kv = kp[s * 64];
-            ur[u][s] += re[s] * kv.x - im[s] * kv.y;
-            ui[u][s] += re[s] * kv.y + im[s] * kv.x;
+          auto load_k = [&](auto ic) WFFT_INLINE { return krow[u * 1024 + decltype(ic)::value * 64]; };
+          wfft64::Pipe16<4, TFHE_K64_DEPTH, cplx> kp;
+          kp.prologue(load_k);
+          kp.run2(load_k, [&](auto i0, const cplx& k0, auto i1, const cplx& k1) WFFT_INLINE {
+            constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;
+            ur[u][s0] += re[s0] * k0.x - im[s0] * k0.y;
+            ui[u][s0] += re[s0] * k0.y + im[s0] * k0.x;
+            ur[u][s1] += re[s1] * k1.x - im[s1] * k1.y;
+            ui[u][s1] += re[s1] * k1.y + im[s1] * k1.x;
           });
         });
-      });
+      }
       static_for<0, 2>([&](auto uc) WFFT_INLINE {
         constexpr int u = decltype(uc)::value;
         double lo_v[16];
         wfft64::inv1024_twisted_real<true>(
             ur[u], ui[u], tile, tb, lane, [&](auto rc, double v) WFFT_INLINE { lo_v[decltype(rc)::value] = v; },
-            [&](auto rc, double v) WFFT_INLINE {
-              // negacyclic product: low half minus high half; the untwist hands hi before lo
-              constexpr int r = decltype(rc)::value;
-              ui[u][r] = v;
-            });
-        static_for<0, 16>([&](auto ic) WFFT_INLINE {
-          constexpr int r = decltype(ic)::value;
-          acc[u][r] = wadd(acc[u][r], round_wrap_i32(lo_v[r] - ui[u][r]));
+            [&](auto rc, double v) WFFT_INLINE { ui[u][decltype(rc)::value] = v; });
+        // negacyclic product = low half - high half of the convolution; acc[u] += it, modulo 2^32
+        static_for<0, 4>([&](auto gc) WFFT_INLINE {
+          constexpr int g = decltype(gc)::value;
+          tb_int4 x = acc_ws[(4 * u + g) * 64];
+          x.x = wadd(x.x, round_wrap_i32(lo_v[4 * g + 0] - ui[u][4 * g + 0]));
+          x.y = wadd(x.y, round_wrap_i32(lo_v[4 * g + 1] - ui[u][4 * g + 1]));
+          x.z = wadd(x.z, round_wrap_i32(lo_v[4 * g + 2] - ui[u][4 * g + 2]));
+          x.w = wadd(x.w, round_wrap_i32(lo_v[4 * g + 3] - ui[u][4 * g + 3]));
+          acc_ws[(4 * u + g) * 64] = x;
         });
       });
     }
     // extract_lwe, src/tlwe.rs:159-180 (k = 1): a[0] = acc0[0], a[j] = -acc0[N-j], b = body[0]
     int32_t* oa = args.out_a + (size_t)b * kN;
-    static_for<0, 16>([&](auto ic) WFFT_INLINE {
-      constexpr int r = decltype(ic)::value;
-      const int t = lane0 + 64 * r;
-      if (t == 0) oa[0] = acc[0][r];
-      else oa[kN - t] = wneg(acc[0][r]);
+    static_for<0, 4>([&](auto gc) WFFT_INLINE {
+      constexpr int g = decltype(gc)::value;
+      const tb_int4 x = acc_ws[g * 64];
+      const int32_t c[4] = {x.x, x.y, x.z, x.w};
+      static_for<0, 4>([&](auto ec) WFFT_INLINE {
+        constexpr int r = 4 * g + decltype(ec)::value;
+        const int t = lane0 + 64 * r;
+        if (t == 0) oa[0] = c[decltype(ec)::value];
+        else oa[kN - t] = wneg(c[decltype(ec)::value]);
+      });
     });
-    if (lane0 == 0) args.out_b[b] = acc[1][0];
+    const tb_int4 body0 = acc_ws[4 * 64];
+    if (lane0 == 0) args.out_b[b] = body0.x;
   }
 }
 
+constexpr int kTbWaves = kWaves64;
+constexpr int kTbLdsBytes = kLds64Bytes;
+
 // One-time transform of the bootstrapping key: wavefront s = ((i l + p) 2 + j) 2 + u writes the
 // spectrum of polynomial u of row (p, j) of bk[i] (flat input [i][p][j][u][N]), scaled by 1/1024.
-__global__ __launch_bounds__(64 * kTbWaves, 1) void bk_fft_textbook_kernel(const int32_t* __restrict__ bk,
+__global__ __launch_bounds__(64 * kTbWaves) void bk_fft_textbook_kernel(const int32_t* __restrict__ bk,
                                                                             const cplx* __restrict__ tables64,
                                                                             cplx* __restrict__ bkfft, int count) {
   __shared__ __attribute__((aligned(16))) char lds[kTbLdsBytes];
-  const wfft64::Tables tb = load_tables64(lds + kTbWaves * wfft64::kTileBytes, tables64);
+  const wfft64::Tables tb = load_tables64(lds + kWaves64 * kWave64Bytes, tables64);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = blockIdx.x * kTbWaves + wave;
   if (s >= count) return;
   const int32_t* p0 = bk + (size_t)s * kN + lane;
   double re[16], im[16];
   static_for<0, 16>([&](auto ic) WFFT_INLINE { re[decltype(ic)::value] = (double)p0[64 * decltype(ic)::value]; });
-  wfft64::fwd1024_twisted_real(re, im, lds + wave * wfft64::kTileBytes, tb, lane);
+  wfft64::fwd1024_twisted_real(re, im, lds + wave * kWave64Bytes, tb, lane);
   cplx* dst = bkfft + (size_t)s * 1024 + lane;
   static_for<0, 16>([&](auto ic) WFFT_INLINE {
     constexpr int p = decltype(ic)::value;
@@ -1990,7 +2033,7 @@ int launch_blind_rotate(tfhe_hip_ctx* ctx, const int32_t* bara, const int32_t* b
   const bool hook = acc_io != nullptr;
 #ifdef TFHE_TEXTBOOK
   {
-    // the textbook build has one mapping: one ciphertext per wavefront, one wavefront per SIMD
+    // the textbook build has one mapping: one ciphertext per wavefront, two wavefronts per SIMD
     if (hook) return fail(ctx, TFHE_HIP_ERR_ARG, "the blind-rotate hook is not part of the textbook build");
     ProfileScope prof(ctx, 1);
     const unsigned grid = (unsigned)std::min<size_t>((B + kTbWaves - 1) / kTbWaves, (size_t)ctx->num_cus);
