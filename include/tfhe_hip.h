@@ -128,7 +128,11 @@ int tfhe_hip_synchronize(tfhe_hip_ctx* ctx);
  *          a third of the latency, 4/3 of the arithmetic.
  * AUTO (default): SPLIT while the batch has at most two ciphertexts per compute
  *          unit; above that whichever throughput form measured faster on MI355X
- *          for the parameter set (l = 2: BATCH64, l = 3: BATCH).
+ *          for the parameter set (l = 2: BATCH64, l = 3: BATCH), which takes the
+ *          batch in whole rounds of one ciphertext per wavefront slot; a remainder of
+ *          at most two ciphertexts per compute unit runs as SPLIT beside the full
+ *          rounds (on a second stream of the context, joined before the call's next
+ *          kernel).
  * Results are identical in every mode. */
 enum { TFHE_HIP_BR_AUTO = 0, TFHE_HIP_BR_BATCH = 1, TFHE_HIP_BR_SPLIT = 2, TFHE_HIP_BR_BATCH64 = 3 };
 int tfhe_hip_set_blind_rotate_mode(tfhe_hip_ctx* ctx, int mode);

@@ -294,15 +294,16 @@ def test_bootstrap_full_size_synthetic_keys(eng, level, B):
         assert (oa[i] == wa).all() and ob[i] == wb and var[i] == wv, i
 
 
-@pytest.mark.parametrize("level", [80, 128])
-def test_blind_rotate_mappings_agree_at_full_size(level):
+@pytest.mark.parametrize("level,B", [(80, 1030), (128, 1030), (80, 2049), (128, 1100)])
+def test_blind_rotate_mappings_agree_at_full_size(level, B):
     """Size-independent property at the bench's parameters: the throughput and
     the low-latency mapping return the same bits on a batch that spans several
-    rounds of persistent workgroups (and the automatic choice equals both)."""
+    rounds of persistent workgroups (and the automatic choice equals both).  In the
+    automatic mode 2 049 gates at l = 2 (rounds of 2 048) and 1 030 / 1 100 at l = 3 (rounds of
+    1 024) leave a remainder that runs in the low-latency mapping on the second stream."""
     import tfhe_amd
     P = orc.params(level)
     K = orc.generate_synthetic_keys(P, 90 + level)
-    B = 1030
     ca = (orc.uniform_i32(91, (B, P.n)), orc.uniform_i32(92, (B,)))
     cb = (orc.uniform_i32(93, (B, P.n)), orc.uniform_i32(94, (B,)))
     out = {}

@@ -2023,6 +2023,43 @@ int launch_prologue(tfhe_hip_ctx* ctx, const int32_t* ca_a, const int32_t* ca_b,
   return 0;
 }
 
+// One launch of one mapping on `stream`.
+int launch_blind_rotate_mode(tfhe_hip_ctx* ctx, int mode, hipStream_t stream, const BlindRotateArgs& a, size_t B) {
+  const bool hook = a.acc_io != nullptr;
+  if (mode == TFHE_HIP_BR_SPLIT) {
+    const dim3 grid((unsigned)B);
+    if (ctx->P.l == 2) {
+      if (hook) hipLaunchKernelGGL((blind_rotate_split_kernel<2, 10, true, 1>), grid, dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((blind_rotate_split_kernel<2, 10, false, 1>), grid, dim3(256), 0, stream, a);
+    } else {
+      if (hook) hipLaunchKernelGGL((blind_rotate_split_kernel<3, 7, true, 2>), grid, dim3(192), 0, stream, a);
+      else hipLaunchKernelGGL((blind_rotate_split_kernel<3, 7, false, 2>), grid, dim3(192), 0, stream, a);
+    }
+  } else if (mode == TFHE_HIP_BR_BATCH64) {
+    const unsigned grid = (unsigned)std::min<size_t>((B + kWaves64 - 1) / kWaves64, (size_t)ctx->num_cus);
+    const dim3 block(64 * kWaves64);
+    if (ctx->P.l == 2) {
+      if (hook) hipLaunchKernelGGL((blind_rotate64_kernel<2, 10, true>), dim3(grid), block, 0, stream, a);
+      else hipLaunchKernelGGL((blind_rotate64_kernel<2, 10, false>), dim3(grid), block, 0, stream, a);
+    } else {
+      if (hook) hipLaunchKernelGGL((blind_rotate64_kernel<3, 7, true>), dim3(grid), block, 0, stream, a);
+      else hipLaunchKernelGGL((blind_rotate64_kernel<3, 7, false>), dim3(grid), block, 0, stream, a);
+    }
+  } else {
+    const unsigned grid = (unsigned)std::min<size_t>((B + kWavesPerBlock - 1) / kWavesPerBlock,
+                                                     (size_t)ctx->num_cus);
+    if (ctx->P.l == 2) {
+      if (hook) hipLaunchKernelGGL((blind_rotate_kernel<2, 10, true>), dim3(grid), dim3(kBlock), 0, stream, a);
+      else hipLaunchKernelGGL((blind_rotate_kernel<2, 10, false>), dim3(grid), dim3(kBlock), 0, stream, a);
+    } else {
+      if (hook) hipLaunchKernelGGL((blind_rotate_kernel<3, 7, true>), dim3(grid), dim3(kBlock), 0, stream, a);
+      else hipLaunchKernelGGL((blind_rotate_kernel<3, 7, false>), dim3(grid), dim3(kBlock), 0, stream, a);
+    }
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
 int launch_blind_rotate(tfhe_hip_ctx* ctx, const int32_t* bara, const int32_t* barb, int32_t mu,
                         int32_t* acc_io, int32_t* out_a, int32_t* out_b, size_t B) {
   BlindRotateArgs a;
@@ -2030,11 +2067,10 @@ int launch_blind_rotate(tfhe_hip_ctx* ctx, const int32_t* bara, const int32_t* b
   a.tables64 = ctx->tables64;
   a.prev_ws = ctx->prev_ws;
   a.acc_io = acc_io; a.out_a = out_a; a.out_b = out_b; a.mu = mu; a.n = ctx->P.n; a.B = (int32_t)B;
-  const bool hook = acc_io != nullptr;
 #ifdef TFHE_TEXTBOOK
   {
     // the textbook build has one mapping: one ciphertext per wavefront, two wavefronts per SIMD
-    if (hook) return fail(ctx, TFHE_HIP_ERR_ARG, "the blind-rotate hook is not part of the textbook build");
+    if (acc_io) return fail(ctx, TFHE_HIP_ERR_ARG, "the blind-rotate hook is not part of the textbook build");
     ProfileScope prof(ctx, 1);
     const unsigned grid = (unsigned)std::min<size_t>((B + kTbWaves - 1) / kTbWaves, (size_t)ctx->num_cus);
     if (ctx->P.l == 2)
@@ -2045,47 +2081,40 @@ int launch_blind_rotate(tfhe_hip_ctx* ctx, const int32_t* bara, const int32_t* b
     return 0;
   }
 #endif
-  // Batches that cannot give every SIMD its own ciphertext run with one
-  // workgroup per ciphertext (2 l wavefronts each, a third of the latency);
-  // larger ones with one persistent workgroup per compute unit (160 KiB of LDS
-  // each), one ciphertext per wavefront.
+  // Batches that cannot give every SIMD its own ciphertext run with one workgroup per
+  // ciphertext (2 l wavefronts each, a third of the latency); larger ones with persistent
+  // workgroups, one ciphertext per wavefront, in whichever of the two throughput forms
+  // measured faster on MI355X for the parameter set.
+  const size_t small = 2 * (size_t)ctx->num_cus;
   int mode = ctx->br_mode;
-  if (mode == TFHE_HIP_BR_AUTO)
-    mode = B <= 2 * (size_t)ctx->num_cus ? TFHE_HIP_BR_SPLIT
-                                         : (ctx->P.l == 2 ? TFHE_HIP_BR_BATCH64 : TFHE_HIP_BR_BATCH);
+  const bool automatic = mode == TFHE_HIP_BR_AUTO;
+  if (automatic)
+    mode = B <= small ? TFHE_HIP_BR_SPLIT : (ctx->P.l == 2 ? TFHE_HIP_BR_BATCH64 : TFHE_HIP_BR_BATCH);
   ProfileScope prof(ctx, 1);
-  if (mode == TFHE_HIP_BR_SPLIT) {
-    const dim3 grid((unsigned)B);
-    if (ctx->P.l == 2) {
-      if (hook) hipLaunchKernelGGL((blind_rotate_split_kernel<2, 10, true, 1>), grid, dim3(256), 0, ctx->stream, a);
-      else hipLaunchKernelGGL((blind_rotate_split_kernel<2, 10, false, 1>), grid, dim3(256), 0, ctx->stream, a);
-    } else {
-      if (hook) hipLaunchKernelGGL((blind_rotate_split_kernel<3, 7, true, 2>), grid, dim3(192), 0, ctx->stream, a);
-      else hipLaunchKernelGGL((blind_rotate_split_kernel<3, 7, false, 2>), grid, dim3(192), 0, ctx->stream, a);
-    }
-  } else if (mode == TFHE_HIP_BR_BATCH64) {
-    const unsigned grid = (unsigned)std::min<size_t>((B + kWaves64 - 1) / kWaves64, (size_t)ctx->num_cus);
-    const dim3 block(64 * kWaves64);
-    if (ctx->P.l == 2) {
-      if (hook) hipLaunchKernelGGL((blind_rotate64_kernel<2, 10, true>), dim3(grid), block, 0, ctx->stream, a);
-      else hipLaunchKernelGGL((blind_rotate64_kernel<2, 10, false>), dim3(grid), block, 0, ctx->stream, a);
-    } else {
-      if (hook) hipLaunchKernelGGL((blind_rotate64_kernel<3, 7, true>), dim3(grid), block, 0, ctx->stream, a);
-      else hipLaunchKernelGGL((blind_rotate64_kernel<3, 7, false>), dim3(grid), block, 0, ctx->stream, a);
-    }
-  } else {
-    const unsigned grid = (unsigned)std::min<size_t>((B + kWavesPerBlock - 1) / kWavesPerBlock,
-                                                     (size_t)ctx->num_cus);
-    if (ctx->P.l == 2) {
-      if (hook) hipLaunchKernelGGL((blind_rotate_kernel<2, 10, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-      else hipLaunchKernelGGL((blind_rotate_kernel<2, 10, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-    } else {
-      if (hook) hipLaunchKernelGGL((blind_rotate_kernel<3, 7, true>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-      else hipLaunchKernelGGL((blind_rotate_kernel<3, 7, false>), dim3(grid), dim3(kBlock), 0, ctx->stream, a);
-    }
+  // A persistent launch takes whole rounds of `slots` ciphertexts: a small remainder would cost
+  // a round of its own.  In automatic mode it goes to the one-workgroup-per-ciphertext mapping
+  // instead, on the context's second stream beside the full rounds (fork and join by events
+  // that exist since tfhe_hip_create: nothing is allocated here).
+  const size_t slots = (size_t)ctx->num_cus * (mode == TFHE_HIP_BR_BATCH64 ? kWaves64 : kWavesPerBlock);
+  const size_t rem = B % slots, full = B - rem;
+  if (automatic && mode != TFHE_HIP_BR_SPLIT && full > 0 && rem > 0 && rem <= small && ctx->aux_stream) {
+    BlindRotateArgs tail = a;
+    tail.bara = bara + full * (size_t)ctx->P.n;
+    if (barb) tail.barb = barb + full;
+    if (acc_io) tail.acc_io = acc_io + full * 3 * kN;
+    if (out_a) tail.out_a = out_a + full * kN;
+    if (out_b) tail.out_b = out_b + full;
+    tail.B = (int32_t)rem;
+    a.B = (int32_t)full;
+    HIP_TRY(ctx, hipEventRecord(ctx->fork_event, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->fork_event, 0));
+    if (int rc = launch_blind_rotate_mode(ctx, TFHE_HIP_BR_SPLIT, ctx->aux_stream, tail, rem)) return rc;
+    HIP_TRY(ctx, hipEventRecord(ctx->join_event, ctx->aux_stream));
+    if (int rc = launch_blind_rotate_mode(ctx, mode, ctx->stream, a, full)) return rc;
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->join_event, 0));
+    return 0;
   }
-  HIP_TRY(ctx, hipGetLastError());
-  return 0;
+  return launch_blind_rotate_mode(ctx, mode, ctx->stream, a, B);
 }
 
 int launch_keyswitch(tfhe_hip_ctx* ctx, const int32_t* in_a, const int32_t* in_b, const int32_t* in2_a,
@@ -2292,6 +2321,13 @@ int tfhe_hip_create(tfhe_hip_ctx** out, int device) {
     tfhe_hip_destroy(ctx);
     return TFHE_HIP_ERR_RUNTIME;
   }
+  // second stream and the two events of the fork / join around a batch's remainder
+  if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->join_event, hipEventDisableTiming) != hipSuccess) {
+    tfhe_hip_destroy(ctx);
+    return TFHE_HIP_ERR_RUNTIME;
+  }
   std::vector<cplx> t64;
   make_tables64(t64);
   double w64[32];
@@ -2330,6 +2366,12 @@ void tfhe_hip_destroy(tfhe_hip_ctx* ctx) {
   if (ctx->tables) (void)hipFree(ctx->tables);
   if (ctx->tables64) (void)hipFree(ctx->tables64);
   if (ctx->prev_ws) (void)hipFree(ctx->prev_ws);
+  if (ctx->aux_stream) {
+    (void)hipStreamSynchronize(ctx->aux_stream);
+    (void)hipStreamDestroy(ctx->aux_stream);
+  }
+  if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
+  if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
   if (ctx->bkfft) (void)hipFree(ctx->bkfft);
   if (ctx->ksblob) (void)hipFree(ctx->ksblob);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
