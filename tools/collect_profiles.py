@@ -78,10 +78,11 @@ def traffic(fetch_pass, write_pass, kernel):
             "traffic_bytes_per_launch": (2 * f["sum"] + w["sum"]) * 1024 / f["dispatches"]}
 
 
-t = traffic("pmc_fetch", "pmc_write", "blind_rotate_kernel")
+bk = "blind_rotate64_kernel" if "blind_rotate64_kernel" in sums["pmc_fetch"] else "blind_rotate_kernel"
+t = traffic("pmc_fetch", "pmc_write", bk)
 t["workload"] = "bench.py default: 16384 NAND gates, Bit80"
 json.dump(t, open(f"{P}/{PRE}_traffic.json", "w"), indent=1)
-pk = "polymul2_kernel" if "polymul2_kernel" in sums["pmc_fetch_polymul"] else "polymul_kernel"
+pk = next(k for k in ("polymul64_kernel", "polymul2_kernel", "polymul_kernel") if k in sums["pmc_fetch_polymul"])
 tp = traffic("pmc_fetch_polymul", "pmc_write_polymul", pk)
 tp["workload"] = "bench.py --workload polymul: 65536 products"
 json.dump(tp, open(f"{P}/{PRE}_traffic_polymul.json", "w"), indent=1)
