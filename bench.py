@@ -61,6 +61,8 @@ def flop_per_iteration(l):
     return 2 * l * FLOP_FFT + 4 * l * (FLOP_POINTWISE + FLOP_FFT)
 
 
+BLIND_ROTATE_MODE = "auto"     # --mode; auto picks blind_rotate64_kernel for batches of this size
+
 LEVELS = {80: dict(n=500, l=2, bg_bit=10), 128: dict(n=630, l=3, bg_bit=7)}
 
 
@@ -493,7 +495,8 @@ def time_nand(eng, torch, dist, dev, world, rank, level, K, B, steps, warmup, ch
         "per_rank_value": per_rank,
         "roofline": {"bound": "fp64_valu",
                      # the throughput form the library's AUTO mode picks for this parameter set
-                     "kernel": "blind_rotate64_kernel" if lv["l"] == 2 else "blind_rotate_kernel",
+                     "kernel": {"batch": "blind_rotate_kernel", "split": "blind_rotate_split_kernel"}.get(
+                         BLIND_ROTATE_MODE, "blind_rotate64_kernel"),
                      "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
                      "measured_fma_stream_peak": FP64_MEASURED_FMA_STREAM_TFLOPS,
@@ -609,6 +612,9 @@ def main():
                     help="strong scaling: this many gates per step over ALL ranks (contiguous shards, "
                          "launches of --batch gates); BASELINE config 4 is --total-gates 1048576")
     ap.add_argument("--workload", default="nand", choices=["nand", "add32", "polymul"])
+    ap.add_argument("--mode", default="auto", choices=["auto", "batch", "split", "batch64"],
+                    help="GPU mapping of the blind rotation (tfhe_hip_set_blind_rotate_mode); results are "
+                         "bit-identical in every mode, auto is what a caller gets")
     ap.add_argument("--keys", default="synthetic", choices=["synthetic", "reference"],
                     help="synthetic: every key entry uniform (no stage degenerates); reference: "
                          "the structure the crate's generate_keys produces")
@@ -631,6 +637,10 @@ def main():
 
     eng = tfhe_amd.Engine(dev.index)
     eng.use_torch_stream()
+    if args.mode != "auto":
+        global BLIND_ROTATE_MODE
+        BLIND_ROTATE_MODE = args.mode
+        eng.set_blind_rotate_mode(args.mode)
 
     def load(level):
         """rank 0 loads and transforms, the device blobs are broadcast once"""

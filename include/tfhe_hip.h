@@ -127,8 +127,8 @@ int tfhe_hip_synchronize(tfhe_hip_ctx* ctx);
  *          result polynomial) pair of tgsw_extern_mul_to_tlwe (src/tgsw.rs:229-264);
  *          a third of the latency, 4/3 of the arithmetic.
  * AUTO (default): SPLIT while the batch has at most two ciphertexts per compute
- *          unit; above that whichever throughput form measured faster on MI355X
- *          for the parameter set (l = 2: BATCH64, l = 3: BATCH), which takes the
+ *          unit; above that BATCH64 (the faster throughput form on MI355X for both
+ *          parameter sets), which takes the
  *          batch in whole rounds of one ciphertext per wavefront slot; a remainder of
  *          at most two ciphertexts per compute unit runs as SPLIT beside the full
  *          rounds (on a second stream of the context, joined before the call's next

@@ -437,7 +437,7 @@ struct BlindRotateArgs {
   const cplx* bkfft;        // [n][l][2][32][64]
   const cplx* tables;       // make_tables: two pairs of 1024-entry tables
   const cplx* tables64;     // make_tables64
-  int32_t* prev_ws;         // blind_rotate64_kernel: [wavefront slots][2][N] previous accumulators
+  int32_t* prev_ws;         // textbook build: [wavefront slots][2][N] accumulators of blind_rotate_textbook_kernel
   int32_t* acc_io;          // hook mode: [B][3][N] accumulators, updated in place
   int32_t* out_a;           // bootstrap mode: [B][N] extracted mask
   int32_t* out_b;           // bootstrap mode: [B]
@@ -920,24 +920,63 @@ __global__ __launch_bounds__(64 * kWaves64) void polymul64_kernel(const int32_t*
 // key loads and waits of one hide behind the arithmetic of the other; and both result
 // polynomials live in the same lanes, so the second product of a level needs no exchange.
 //
-// Lane `lane`, register r holds coefficient lane + 64 r of a polynomial.  Per wavefront: the
-// accumulator acc[2][16] in registers; in LDS the exchange tile (which also stages prev + acc
-// for the rotation) and the sample being decomposed (XORed with tt_mask) as lane-private
-// 16-byte granules; the previous accumulator, touched once per iteration, in a workspace in
-// global memory (8 KiB per wavefront slot, L2 resident) as lane-private 16-byte granules:
-// 256 registers and 18 KiB of LDS per wavefront hold nothing more.
+// Lane `lane`, register r holds coefficient lane + 64 r of a polynomial.  Everything a
+// ciphertext needs between iterations stays on the chip: the accumulator acc[2][16] and the
+// sample being decomposed (PackedSample: only the bits the levels read, 20 - 22 registers) in
+// registers; the previous accumulator, touched once per iteration, in 8 KiB of the wavefront's
+// LDS share (which also stages prev + acc for the rotation) next to the 9 KiB exchange tile.
+// Global memory is read for the key and the rotation amounts and written for the result only.
 // The key is the one blind_rotate_kernel reads ([n][l][block][32][64], half-wave (h, q),
 // register p_old: value q + 32 br5(p_old) of K_{h,h} / K_{h,1-h}): wave_fft64.hpp's spectrum
 // layout wants value kr + 16 c + 64 br4(p) in lane (kr3 kr2 c1 c0 kr1 kr0), register p, which is
 // q = kr + 16 (c & 1), p_old = p + 16 (c >> 1): a per-lane base address, then the same
 // register stride.
 // ---------------------------------------------------------------------------
-constexpr int kTt64Bytes = 2 * kN * 4;
-static_assert(wfft64::kTileBytes >= 2 * kN * 4, "the tile stages prev + acc of both polynomials");
-static_assert(wfft64::kTileBytes + kTt64Bytes == kWave64Bytes, "one LDS share for both wavefront-per-transform kernels");
+constexpr int kPrev64Bytes = 2 * kN * 4;
+static_assert(wfft64::kTileBytes + kPrev64Bytes == kWave64Bytes, "one LDS share for both wavefront-per-transform kernels");
 #ifndef TFHE_K64_DEPTH
 #define TFHE_K64_DEPTH 3
 #endif
+// The wavefronts of a workgroup meet at a barrier every TFHE_ITER_BARRIER iterations (a power of
+// two, 0 = never).  Without it the two wavefronts of a SIMD drift apart (the older one is served
+// first) until every wavefront streams the key on its own: 18 GB instead of 4 GB fetched per
+// 16 384-gate launch, and 5 % more time.
+#ifndef TFHE_ITER_BARRIER
+#define TFHE_ITER_BARRIER 8
+#endif
+
+// The sample being decomposed, XORed with tt_mask, packed into registers: a level only reads
+// the top KEEP = l bg_bit bits of a coefficient.  For coefficient t = lane + 64 r, word[r] holds
+// those bits of polynomial 0 where they are (bits 31 .. 32 - KEEP) and the top 32 - KEEP bits of
+// polynomial 1 below them; the remaining REM = 2 KEEP - 32 bits of polynomial 1 are packed PER to a
+// word in rem[].  20 registers for l = 2, Bg = 2^10 and 22 for l = 3, Bg = 2^7 instead of 32, which
+// is what lets the sample stay in registers and the previous accumulator take its place in LDS.
+template <int L, int BGBIT>
+struct PackedSample {
+  static constexpr int KEEP = L * BGBIT;
+  static constexpr int REM = 2 * KEEP - 32;
+  static_assert(KEEP < 32 && REM > 0 && REM <= 16, "packing of the decomposed sample");
+  static constexpr int PER = 32 / REM;
+  static constexpr int NREM = (16 + PER - 1) / PER;
+  uint32_t word[16];
+  uint32_t rem[NREM];
+
+  // x0, x1: coefficient lane + 64 r of polynomials 0 and 1 (already XORed with tt_mask)
+  template <int R>
+  __device__ __forceinline__ void put(uint32_t x0, uint32_t x1) {
+    word[R] = (x0 & (~0u << (32 - KEEP))) | (x1 >> KEEP);
+    const uint32_t rest = __builtin_amdgcn_ubfe(x1, 32 - KEEP, REM);
+    if constexpr (R % PER == 0) rem[R / PER] = rest;
+    else rem[R / PER] |= rest << ((R % PER) * REM);
+  }
+  // the word whose bit field [decal, decal + bg_bit) is digit p of polynomial H, coefficient lane + 64 R
+  template <int H, int R>
+  __device__ __forceinline__ uint32_t get() const {
+    if constexpr (H == 0) return word[R];
+    else
+      return (word[R] << KEEP) | (__builtin_amdgcn_ubfe(rem[R / PER], (R % PER) * REM, REM) << (32 - KEEP));
+  }
+};
 
 struct RegisterSink64 {
   int32_t (&acc)[2][16];
@@ -953,32 +992,30 @@ struct RegisterSink64 {
 // their twisted transform D_h, and the products D_h K_{h,h} -> result polynomial h and
 // D_h K_{h,1-h} -> result polynomial 1 - h, each rounded and saturated on its own before the
 // wrapping add.  bk_level: [2][32][64] complex (block, register, lane of blind_rotate_kernel).
-template <int BGBIT, class M>
-__device__ __forceinline__ void level_product64(int p, const char* tt_lds, const cplx* __restrict__ bk_level,
+template <int BGBIT, class TT, class M>
+__device__ __forceinline__ void level_product64(int p, const TT& tt, const cplx* __restrict__ bk_level,
                                                 int32_t (&acc)[2][16], char* tile, const wfft64::Tables& tb,
                                                 int lane, M& margin) {
-  typedef int int4v __attribute__((ext_vector_type(4)));
   const int decal = 32 - (p + 1) * BGBIT;
-  const int4v* tt = reinterpret_cast<const int4v*>(tt_lds) + lane;      // granule (h, g) at [(4 h + g) * 64]
   static_for<0, 2>([&](auto hc) WFFT_INLINE {
     constexpr int h = decltype(hc)::value;
     double re[16], im[16], zr[16], zi[16];
-    wfft::wave_lds_fence();
-    static_for<0, 4>([&](auto gc) WFFT_INLINE {
-      constexpr int g = decltype(gc)::value;
-      const int4v t = tt[(4 * h + g) * 64];
-      re[4 * g + 0] = (double)(int32_t)__builtin_amdgcn_sbfe(t.x, decal, BGBIT);
-      re[4 * g + 1] = (double)(int32_t)__builtin_amdgcn_sbfe(t.y, decal, BGBIT);
-      re[4 * g + 2] = (double)(int32_t)__builtin_amdgcn_sbfe(t.z, decal, BGBIT);
-      re[4 * g + 3] = (double)(int32_t)__builtin_amdgcn_sbfe(t.w, decal, BGBIT);
+    static_for<0, 16>([&](auto rc) WFFT_INLINE {
+      constexpr int r = decltype(rc)::value;
+      re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(tt.template get<h, r>(), decal, BGBIT);
     });
     // this lane's spectrum values in the half-wave layout of the key (see the kernel's comment)
     const int key_lane = (((lane >> 3) & 1) * 16) * 64 + h * 32 + (((lane >> 4) << 2) | (lane & 3)) +
                          16 * ((lane >> 2) & 1);
     const cplx* ka = bk_level + key_lane;
     const cplx* kb = bk_level + 2048 + key_lane;
+#ifdef TFHE_ABLATE_KEY
+    auto load_a = [&](auto ic) WFFT_INLINE { (void)ka; return cplx{0.75 + decltype(ic)::value, 0.5}; };
+    auto load_b = [&](auto ic) WFFT_INLINE { (void)kb; return cplx{0.25 + decltype(ic)::value, 1.5}; };
+#else
     auto load_a = [&](auto ic) WFFT_INLINE { return ka[decltype(ic)::value * 64]; };
     auto load_b = [&](auto ic) WFFT_INLINE { return kb[decltype(ic)::value * 64]; };
+#endif
     wfft64::fwd1024_twisted_real(re, im, tile, tb, lane);
     {
       // Z = D_h K_{h,h} into registers of its own: D_h stays where it is for the second product
@@ -1011,18 +1048,21 @@ __device__ __forceinline__ void level_product64(int p, const char* tt_lds, const
 }
 
 // t = X^abar (prev + acc) - acc for polynomials 0 and 1 (src/bootstrapping.rs:136-146,
-// src/polynomial.rs:281-313) into tt_lds (XORed with mask, see tt_mask; lane-private 16-byte
-// granules), then prev <- acc.  prev_ws: this wavefront's previous accumulator in global memory,
-// as lane-private 16-byte granules ((h, g) at [(4 h + g) * 64 + lane]); have_prev = false stands
-// for the all-zero previous accumulator a blind rotation starts with.  GENERAL as in rotate_diff.
-template <bool GENERAL>
-__device__ __forceinline__ void rotate_diff64(const int32_t (&acc)[2][16], int abar, char* tile, char* tt_lds,
-                                              int32_t* __restrict__ prev_ws, bool have_prev, int lane,
-                                              uint32_t mask) {
+// src/polynomial.rs:281-313), XORed with mask (see tt_mask) and packed into tt; then prev <- acc.
+// prev_lds: 8 KiB of this wavefront's LDS share.  Between iterations it holds the previous
+// accumulator as lane-private 16-byte granules ((h, g) at [(4 h + g) * 64 + lane]); during the
+// rotation it stages prev + acc in coefficient order for the gather.  A wavefront's LDS
+// operations execute in program order, so the phases need no wait between them.
+// have_prev = false stands for the all-zero previous accumulator a blind rotation starts with.
+// GENERAL as in rotate_diff.
+template <bool GENERAL, class TT>
+__device__ __forceinline__ void rotate_diff64(const int32_t (&acc)[2][16], int abar, char* prev_lds, bool have_prev,
+                                              int lane, uint32_t mask, TT& tt) {
   typedef int int4v __attribute__((ext_vector_type(4)));
-  int32_t* S = reinterpret_cast<int32_t*>(tile);                  // [2][N]: prev + acc
-  int4v* pv = reinterpret_cast<int4v*>(prev_ws) + lane;
+  int32_t* S = reinterpret_cast<int32_t*>(prev_lds);               // [2][N]: prev + acc
+  int4v* pv = reinterpret_cast<int4v*>(prev_lds) + lane;
   int32_t v[2][16];
+  wfft::wave_lds_fence();
   if (have_prev) {
     static_for<0, 8>([&](auto ic) WFFT_INLINE {
       constexpr int h = decltype(ic)::value >> 2, g = decltype(ic)::value & 3;
@@ -1036,10 +1076,6 @@ __device__ __forceinline__ void rotate_diff64(const int32_t (&acc)[2][16], int a
   static_for<0, 32>([&](auto ic) WFFT_INLINE {
     constexpr int h = decltype(ic)::value >> 4, r = decltype(ic)::value & 15;
     S[h * kN + lane + 64 * r] = wadd(v[h][r], acc[h][r]);
-  });
-  static_for<0, 8>([&](auto ic) WFFT_INLINE {
-    constexpr int h = decltype(ic)::value >> 2, g = decltype(ic)::value & 3;
-    pv[(4 * h + g) * 64] = int4v{acc[h][4 * g], acc[h][4 * g + 1], acc[h][4 * g + 2], acc[h][4 * g + 3]};
   });
   wfft::wave_lds_fence();
   // coefficient n comes from (n - pw) mod N, negated as rotate_diff explains
@@ -1058,16 +1094,21 @@ __device__ __forceinline__ void rotate_diff64(const int32_t (&acc)[2][16], int a
     v[h][r] = S[h * kN + ((base + 64 * r) & (kN - 1))];
   });
   wfft::wave_lds_fence();
-  static_for<0, 32>([&](auto ic) WFFT_INLINE {
-    constexpr int h = decltype(ic)::value >> 4, r = decltype(ic)::value & 15;
-    const bool neg = GENERAL ? ((base < -64 * r) != cycle) : (wrap < -64 * r);
-    const int32_t x = neg ? wneg(v[h][r]) : v[h][r];
-    v[h][r] = (int32_t)((uint32_t)wsub(x, acc[h][r]) ^ mask);
-  });
-  int4v* tt = reinterpret_cast<int4v*>(tt_lds) + lane;
   static_for<0, 8>([&](auto ic) WFFT_INLINE {
     constexpr int h = decltype(ic)::value >> 2, g = decltype(ic)::value & 3;
-    tt[(4 * h + g) * 64] = int4v{v[h][4 * g], v[h][4 * g + 1], v[h][4 * g + 2], v[h][4 * g + 3]};
+    pv[(4 * h + g) * 64] = int4v{acc[h][4 * g], acc[h][4 * g + 1], acc[h][4 * g + 2], acc[h][4 * g + 3]};
+  });
+  wfft::wave_lds_fence();
+  static_for<0, 16>([&](auto rc) WFFT_INLINE {
+    constexpr int r = decltype(rc)::value;
+    uint32_t x[2];
+    static_for<0, 2>([&](auto hc) WFFT_INLINE {
+      constexpr int h = decltype(hc)::value;
+      const bool neg = GENERAL ? ((base < -64 * r) != cycle) : (wrap < -64 * r);
+      const int32_t y = neg ? wneg(v[h][r]) : v[h][r];
+      x[h] = (uint32_t)wsub(y, acc[h][r]) ^ mask;
+    });
+    tt.template put<r>(x[0], x[1]);
   });
 }
 
@@ -1078,11 +1119,10 @@ __global__ __launch_bounds__(64 * kWaves64) void blind_rotate64_kernel(BlindRota
   const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   char* tile = lds + wave * kWave64Bytes;
-  char* tt_lds = tile + wfft64::kTileBytes;
+  char* prev_lds = tile + wfft64::kTileBytes;
   // persistent workgroups: wavefront slot s takes ciphertexts s, s + slots, ...
   const int slot = blockIdx.x * kWaves64 + wave;
   const int slots = gridDim.x * kWaves64;
-  int32_t* prev_ws = args.prev_ws + (size_t)slot * 2 * kN;
   NoMargin no_margin;
 
 #pragma unroll 1
@@ -1099,16 +1139,22 @@ __global__ __launch_bounds__(64 * kWaves64) void blind_rotate64_kernel(BlindRota
 #pragma unroll 1
     for (int i = 0; i < args.n; i++) {
       if ((i & 63) == 0) abar64 = (i + lane0 < args.n) ? bara[i + lane0] : 0;
+#if TFHE_ITER_BARRIER
+      // the wavefronts of a workgroup walk the key together (wavefronts that have finished do
+      // not count for the barrier)
+      if ((i & (TFHE_ITER_BARRIER - 1)) == 0) __builtin_amdgcn_s_barrier();
+#endif
       const int abar = __builtin_amdgcn_readlane(abar64, i & 63);
       if (abar == 0) continue;                                   // bootstrapping.rs:122-126
       int lane = lane0;
       asm volatile("" : "+v"(lane));
-      rotate_diff64<HOOK>(acc, abar, tile, tt_lds, prev_ws, have_prev, lane, tt_mask<L, BGBIT>());   // also prev <- acc
+      PackedSample<L, BGBIT> tt;
+      rotate_diff64<HOOK>(acc, abar, prev_lds, have_prev, lane, tt_mask<L, BGBIT>(), tt);   // also prev <- acc
       have_prev = true;
       const cplx* bk_i = args.bkfft + (size_t)i * L * 4 * 1024;
 #pragma unroll 1
       for (int p = 0; p < L; p++)
-        level_product64<BGBIT>(p, tt_lds, bk_i + (size_t)p * 4 * 1024, acc, tile, tb, lane, no_margin);
+        level_product64<BGBIT>(p, tt, bk_i + (size_t)p * 4 * 1024, acc, tile, tb, lane, no_margin);
     }
 
     if (HOOK) {
@@ -1929,8 +1975,10 @@ int alloc_keys(tfhe_hip_ctx* ctx, const tfhe_hip_params* p) {
   blob_sizes(p, &ctx->bk_bytes, &ctx->ks_bytes, &ctx->ks_rows_bytes);
   HIP_TRY(ctx, hipMalloc((void**)&ctx->bkfft, ctx->bk_bytes));
   HIP_TRY(ctx, hipMalloc((void**)&ctx->ksblob, ctx->ks_bytes));
-  if (!ctx->prev_ws)       // one slot per wavefront of a full blind_rotate64_kernel launch
+#ifdef TFHE_TEXTBOOK
+  if (!ctx->prev_ws)       // one slot per wavefront of a full blind_rotate_textbook_kernel launch
     HIP_TRY(ctx, hipMalloc((void**)&ctx->prev_ws, (size_t)ctx->num_cus * kWaves64 * 2 * kN * sizeof(int32_t)));
+#endif
   return 0;
 }
 
@@ -2083,13 +2131,13 @@ int launch_blind_rotate(tfhe_hip_ctx* ctx, const int32_t* bara, const int32_t* b
 #endif
   // Batches that cannot give every SIMD its own ciphertext run with one workgroup per
   // ciphertext (2 l wavefronts each, a third of the latency); larger ones with persistent
-  // workgroups, one ciphertext per wavefront, in whichever of the two throughput forms
-  // measured faster on MI355X for the parameter set.
+  // workgroups, one ciphertext per wavefront, two wavefronts per SIMD (the faster of the two
+  // throughput forms on MI355X for both parameter sets).
   const size_t small = 2 * (size_t)ctx->num_cus;
   int mode = ctx->br_mode;
   const bool automatic = mode == TFHE_HIP_BR_AUTO;
   if (automatic)
-    mode = B <= small ? TFHE_HIP_BR_SPLIT : (ctx->P.l == 2 ? TFHE_HIP_BR_BATCH64 : TFHE_HIP_BR_BATCH);
+    mode = B <= small ? TFHE_HIP_BR_SPLIT : TFHE_HIP_BR_BATCH64;
   ProfileScope prof(ctx, 1);
   // A persistent launch takes whole rounds of `slots` ciphertexts: a small remainder would cost
   // a round of its own.  In automatic mode it goes to the one-workgroup-per-ciphertext mapping

@@ -150,8 +150,10 @@ struct Pipe16 {
   }
 };
 
+// Twiddles are fetched two at a time: a group of four costs the blind rotation the registers
+// that keep its decomposed sample out of scratch memory.
 #ifndef WFFT64_TW_GROUP
-#define WFFT64_TW_GROUP 4
+#define WFFT64_TW_GROUP 2
 #endif
 
 // ---- step 3: lane bits <-> register bits ---------------------------------------------------
@@ -187,6 +189,62 @@ __device__ __forceinline__ void exchange_lane_bits(double (&re)[16], double (&im
     swap_f64<true>(re[br4(x)], re[br4(x | 4)]);
     swap_f64<true>(im[br4(x)], im[br4(x | 4)]);
   });
+}
+
+// The same exchange through the wavefront's tile: every lane stores its 16 registers and loads
+// the 16 that belong to it afterwards (one 8-byte access per register each way, real and
+// imaginary parts one after the other).  A v_permlane*_swap costs a SIMD about 3 ns beside a
+// stream of v_fma_f64 from a second wavefront, a ds_write_b64 2 ns and an 8-byte read under
+// 1 ns, and a swap moves two registers where the LDS pair moves one each way: 64 swaps against
+// 32 + 32 LDS accesses per transform.
+// Tile layout (f64 units): [xhi][a][xlo][ql] with kExchStride per xhi, where the writer is lane
+// (a | ql) and (xhi, xlo) its logical register index; lane (A | ql) then reads, for its new
+// logical register (yhi, ylo), the entry [A][yhi][ylo][ql].  The 16 f64 of padding per xhi put
+// the 8-byte reads of lanes (A, ql) and (A + 1, ql) on different halves of the 64 banks.
+#ifndef WFFT64_LDS_EXCHANGE
+#define WFFT64_LDS_EXCHANGE 0
+#endif
+constexpr int kExchStride = 4 * 4 * 16 + 16;
+static_assert(4 * kExchStride * 8 <= kTileBytes, "the exchange fits the transpose tile");
+struct ExchAddr {
+  char* w;          // + ((x >> 2) * kExchStride + (x & 3) * 16) * 8: where this lane stores logical register x
+  const char* r;    // + ((y >> 2) * 64 + (y & 3) * 16) * 8: where its new logical register y waits
+};
+__device__ __forceinline__ ExchAddr exch_addr(char* tile, int lane) {
+  const int a = lane >> 4, ql = lane & 15;
+  return {tile + (a * 64 + ql) * 8, tile + (a * kExchStride + ql) * 8};
+}
+template <int BYTE_OFFSET>
+__device__ __forceinline__ void exch_store(const ExchAddr& t, double x) {
+  typedef __attribute__((address_space(3))) char* lds_ptr;
+  const unsigned a = (unsigned)(uintptr_t)(lds_ptr)t.w;
+  asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(a), "v"(x), "n"(BYTE_OFFSET) : "memory");
+}
+__device__ __forceinline__ void exchange_component_lds(double (&v)[16], const ExchAddr& t) {
+  static_for<0, 16>([&](auto ic) WFFT_INLINE {
+    constexpr int x = decltype(ic)::value;
+    exch_store<((x >> 2) * kExchStride + (x & 3) * 16) * 8>(t, v[br4(x)]);
+  });
+  wave_lds_fence();
+  static_for<0, 16>([&](auto ic) WFFT_INLINE {
+    constexpr int y = decltype(ic)::value;
+    v[br4(y)] = *reinterpret_cast<const double*>(t.r + ((y >> 2) * 64 + (y & 3) * 16) * 8);
+  });
+  wave_lds_fence();
+}
+__device__ __forceinline__ void exchange_lane_bits(double (&re)[16], double (&im)[16], char* tile, int lane) {
+#ifdef WFFT64_ABLATE_SWAP
+  (void)tile; (void)lane; (void)re; (void)im;
+#elif WFFT64_LDS_EXCHANGE
+  const ExchAddr t = exch_addr(tile, lane);
+  wave_lds_fence();
+  exchange_component_lds(re, t);
+  exchange_component_lds(im, t);
+#else
+  (void)tile;
+  (void)lane;
+  exchange_lane_bits(re, im);
+#endif
 }
 
 // ---- step 4: 4-point DFT over logical bits (3, 2), in place ---------------------------------
@@ -227,6 +285,10 @@ struct TileAddr {
 #endif
 template <int ROW>
 __device__ __forceinline__ void tile_store(const TileAddr& t, double x) {
+#ifdef WFFT64_ABLATE_TRANSPOSE
+  (void)t; (void)x;
+  return;
+#endif
 #if WFFT64_ASM_STORE
   typedef __attribute__((address_space(3))) char* lds_ptr;
   const unsigned a = (unsigned)(uintptr_t)(lds_ptr)t.w;
@@ -245,6 +307,10 @@ __device__ __forceinline__ TileAddr tile_addr(char* tile, int lane) {
 // physical register br4(i) (else i); LOAD_BR likewise for the registers that receive the row.
 template <bool STORE_BR, bool LOAD_BR>
 __device__ __forceinline__ void row_transpose_load(double (&v)[16], const TileAddr& t) {
+#ifdef WFFT64_ABLATE_TRANSPOSE
+  (void)t; (void)v;
+  return;
+#endif
   wave_lds_fence();
   static_for<0, 8>([&](auto gc) WFFT_INLINE {
     constexpr int g = decltype(gc)::value;
@@ -287,14 +353,18 @@ __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[16], double (&
   wave_lds_fence();
   {
     Pipe16<WFFT64_TW_GROUP, 1, cplx> pipe;
+#ifdef WFFT64_ABLATE_T1
+    auto load = [&](auto ic) WFFT_INLINE { return cplx{0.75 + decltype(ic)::value, 0.5}; };
+#else
     auto load = [&](auto ic) WFFT_INLINE { return tb.t1[br4(decltype(ic)::value) * 64 + lane]; };
+#endif
     pipe.prologue(load);
     pipe.run2(load, [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
       constexpr int p0 = decltype(i0)::value, p1 = decltype(i1)::value;      // physical: kr = br4(p)
       wfft::cmul2<false>(re[p0], im[p0], w0, re[p1], im[p1], w1);
     });
   }
-  exchange_lane_bits(re, im);
+  exchange_lane_bits(re, im, tile, lane);
   dft4_high_bits<false>(re, im);
   const TileAddr ta = tile_addr(tile, lane);
   {
@@ -343,11 +413,15 @@ __device__ __forceinline__ void inv1024_twisted_real(double (&re)[16], double (&
     });
   }
   dft4_high_bits<true>(re, im);
-  exchange_lane_bits(re, im);
+  exchange_lane_bits(re, im, tile, lane);
   wave_lds_fence();
   {
     Pipe16<WFFT64_TW_GROUP, 1, cplx> pipe;
+#ifdef WFFT64_ABLATE_T1
+    auto load = [&](auto ic) WFFT_INLINE { return cplx{0.75 + decltype(ic)::value, 0.5}; };
+#else
     auto load = [&](auto ic) WFFT_INLINE { return tb.t1[br4(decltype(ic)::value) * 64 + lane]; };
+#endif
     pipe.prologue(load);
     pipe.run2(load, [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
       constexpr int p0 = decltype(i0)::value, p1 = decltype(i1)::value;
