@@ -844,7 +844,7 @@ __global__ __launch_bounds__(64 * kWaves64) void polymul64_kernel(const int32_t*
         constexpr int r = decltype(ic)::value;
         re[r] = (double)in[64 * r];
       });
-      wfft64::fwd1024_twisted_real(re, im, tile, tb, lane);
+      wfft64::fwd1024_twisted_real<4>(re, im, tile, tb, lane);
       static_for<0, 16>([&](auto ic) WFFT_INLINE {
         constexpr int p = decltype(ic)::value;
         pre[p] = re[p];
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(64 * kWaves64) void polymul64_kernel(const int32_t*
       });
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (prod + stride < B) fetch(prod + stride, lane);
-      wfft64::fwd1024_twisted_real(re, im, tile, tb, lane);
+      wfft64::fwd1024_twisted_real<4>(re, im, tile, tb, lane);
     }
     __builtin_amdgcn_sched_barrier(0);
     wfft::chunked_for32<4>([&](auto ic) WFFT_INLINE {
@@ -872,7 +872,7 @@ __global__ __launch_bounds__(64 * kWaves64) void polymul64_kernel(const int32_t*
     __builtin_amdgcn_sched_barrier(0);
     const int lane = fresh_lane();
     // afterwards re = coefficients t < N, im = coefficients N + t of this product, t = lane + 64 r
-    wfft64::inv1024_twisted_real<!ACCUMULATE>(
+    wfft64::inv1024_twisted_real<!ACCUMULATE, 4>(
         re, im, tile, tb, lane,
         [&](auto rc, double v) WFFT_INLINE { re[decltype(rc)::value] = v; },
         [&](auto rc, double v) WFFT_INLINE { im[decltype(rc)::value] = v; });
@@ -891,22 +891,42 @@ __global__ __launch_bounds__(64 * kWaves64) void polymul64_kernel(const int32_t*
         margin[2 * (size_t)prod + 0] = mg.all;
         margin[2 * (size_t)prod + 1] = mg.deciding;
       }
-    } else if (ACCUMULATE) {
-      int32_t* dst = out + (size_t)prod * kN + lane;
-      int32_t old[16];
-      static_for<0, 16>([&](auto ic) WFFT_INLINE { old[decltype(ic)::value] = dst[64 * decltype(ic)::value]; });
-      static_for<0, 16>([&](auto ic) WFFT_INLINE {
-        constexpr int r = decltype(ic)::value;
-        dst[64 * r] = wadd(old[r], wfft::round_sat_i32(re[r]));
-      });
     } else {
-      int32_t* lo_p = out + (size_t)prod * (2 * kN - 1) + lane;
-      int32_t* hi_p = lo_p + kN;
+      // The rounded coefficients go through the (now free) tile in coefficient order, so that a
+      // lane stores 16 contiguous bytes: 4 + 4 or 8 wide accesses instead of 16 + 16 or 32 of four
+      // bytes (the narrow stores cost the full product a tenth of its time).  Rows of the full
+      // form are 2N - 1 words long, i.e. 4-byte aligned only, which the wide accesses allow.
+      typedef int int4u __attribute__((ext_vector_type(4), aligned(4)));
+      typedef int int3u __attribute__((ext_vector_type(3), aligned(4)));
+      typedef int int4v __attribute__((ext_vector_type(4)));
+      int32_t* T = reinterpret_cast<int32_t*>(tile);
+      wfft::wave_lds_fence();
       static_for<0, 16>([&](auto ic) WFFT_INLINE {
         constexpr int r = decltype(ic)::value;
-        lo_p[64 * r] = wfft::round_sat_i32(re[r]);
-        if (r < 15 || lane < 63) hi_p[64 * r] = wfft::round_sat_i32(im[r]);      // 2N-1 coefficients
+        T[lane + 64 * r] = wfft::round_sat_i32(re[r]);
+        if (!ACCUMULATE) T[kN + lane + 64 * r] = wfft::round_sat_i32(im[r]);
       });
+      wfft::wave_lds_fence();
+      const int4v* Q = reinterpret_cast<const int4v*>(tile) + lane;      // coefficients 4 lane + 256 j ..
+      if (ACCUMULATE) {
+        int4u* dst = reinterpret_cast<int4u*>(out + (size_t)prod * kN + 4 * lane);
+        int4v old[4];
+        static_for<0, 4>([&](auto jc) WFFT_INLINE { old[decltype(jc)::value] = dst[64 * decltype(jc)::value]; });
+        static_for<0, 4>([&](auto jc) WFFT_INLINE {
+          constexpr int j = decltype(jc)::value;
+          const int4v q = Q[64 * j];
+          dst[64 * j] = int4v{wadd(old[j].x, q.x), wadd(old[j].y, q.y), wadd(old[j].z, q.z), wadd(old[j].w, q.w)};
+        });
+      } else {
+        int32_t* dst = out + (size_t)prod * (2 * kN - 1) + 4 * lane;
+        static_for<0, 8>([&](auto jc) WFFT_INLINE {
+          constexpr int j = decltype(jc)::value;
+          const int4v q = Q[64 * j];
+          if (j < 7 || lane < 63) *reinterpret_cast<int4u*>(dst + 256 * j) = q;
+          else *reinterpret_cast<int3u*>(dst + 256 * j) = int3u{q.x, q.y, q.z};     // 2N - 1 coefficients
+        });
+      }
+      wfft::wave_lds_fence();
     }
   }
 }
@@ -1265,6 +1285,9 @@ __global__ __launch_bounds__(64 * kWaves64) void blind_rotate_textbook_kernel(Bl
 #pragma unroll 1
     for (int i = 0; i < args.n; i++) {
       if ((i & 63) == 0) abar64 = (i + lane0 < args.n) ? bara[i + lane0] : 0;
+#if TFHE_ITER_BARRIER
+      if ((i & (TFHE_ITER_BARRIER - 1)) == 0) __builtin_amdgcn_s_barrier();      // as blind_rotate64_kernel
+#endif
       const int abar = __builtin_amdgcn_readlane(abar64, i & 63);
       if (abar == 0) continue;
       int lane = lane0;

@@ -150,8 +150,9 @@ struct Pipe16 {
   }
 };
 
-// Twiddles are fetched two at a time: a group of four costs the blind rotation the registers
-// that keep its decomposed sample out of scratch memory.
+// Default size of the groups in which the T1 twiddles are fetched (template parameter TWG of the
+// transforms): two at a time, because a group of four costs the blind rotation the registers that
+// keep its decomposed sample out of scratch memory; the isolated product has room for four.
 #ifndef WFFT64_TW_GROUP
 #define WFFT64_TW_GROUP 2
 #endif
@@ -269,6 +270,52 @@ __device__ __forceinline__ void dft4_high_bits(double (&re)[16], double (&im)[16
   });
 }
 
+// The inverse 4-point pass with the conjugated T2 twiddles on its inputs, x[c] conj(w)^c with
+// w = w1 (w2 = w1^2), as four decimation-in-time butterflies a +- v b of six FMAs each:
+//   s, d = x0 +- conj(w2) x2      t, u = x1 +- conj(w2) x3
+//   X0, X2 = s +- conj(w1) t      X1, X3 = d +- i conj(w1) u
+// 24 instructions for four points instead of three complex products and sixteen additions (28).
+// v = (vr, vi) comes in vector registers; the new a returns in fresh registers, b in place.
+__device__ __forceinline__ void dit_butterfly2_v(double a0r, double a0i, double& b0r, double& b0i, double vr0,
+                                                 double vi0, double& n0r, double& n0i, double a1r, double a1i,
+                                                 double& b1r, double& b1i, double vr1, double vi1, double& n1r,
+                                                 double& n1i) {
+  asm("v_fma_f64 %0, -%5, %13, %8\n\tv_fma_f64 %1, %5, %12, %9\n\t"
+      "v_fma_f64 %2, -%7, %15, %10\n\tv_fma_f64 %3, %7, %14, %11\n\t"
+      "v_fma_f64 %0, %4, %12, %0\n\tv_fma_f64 %1, %4, %13, %1\n\t"
+      "v_fma_f64 %2, %6, %14, %2\n\tv_fma_f64 %3, %6, %15, %3\n\t"
+      "v_fma_f64 %4, 2.0, %8, -%0\n\tv_fma_f64 %5, 2.0, %9, -%1\n\t"
+      "v_fma_f64 %6, 2.0, %10, -%2\n\tv_fma_f64 %7, 2.0, %11, -%3"
+      : "=&v"(n0r), "=&v"(n0i), "=&v"(n1r), "=&v"(n1i), "+v"(b0r), "+v"(b0i), "+v"(b1r), "+v"(b1i)
+      : "v"(a0r), "v"(a0i), "v"(a1r), "v"(a1i), "v"(vr0), "v"(vi0), "v"(vr1), "v"(vi1));
+}
+#ifndef WFFT64_FUSED_T2
+#define WFFT64_FUSED_T2 1
+#endif
+// w1 = w64^ql, w2 = w64^(2 ql) as stored in T2 (not conjugated)
+__device__ __forceinline__ void inv_dft4_with_t2(double (&re)[16], double (&im)[16], const cplx& w1, const cplx& w2) {
+  const double m1i = -w1.y, m2i = -w2.y;                        // conj(w) = (w.x, -w.y)
+  static_for<0, 2>([&](auto jc) WFFT_INLINE {
+    constexpr int j0 = 2 * decltype(jc)::value, j1 = j0 + 1;    // two groups of four points at a time
+    constexpr int a0 = br4(j0), a1 = br4(4 + j0), a2 = br4(8 + j0), a3 = br4(12 + j0);
+    constexpr int b0 = br4(j1), b1 = br4(4 + j1), b2 = br4(8 + j1), b3 = br4(12 + j1);
+    double sr0, si0, sr1, si1, tr0, ti0, tr1, ti1;
+    // s = x0 + conj(w2) x2 (fresh), x2 <- d;   t = x1 + conj(w2) x3 (fresh), x3 <- u
+    dit_butterfly2_v(re[a0], im[a0], re[a2], im[a2], w2.x, m2i, sr0, si0, re[b0], im[b0], re[b2], im[b2], w2.x, m2i,
+                     sr1, si1);
+    dit_butterfly2_v(re[a1], im[a1], re[a3], im[a3], w2.x, m2i, tr0, ti0, re[b1], im[b1], re[b3], im[b3], w2.x, m2i,
+                     tr1, ti1);
+    double x0r, x0i, x1r, x1i, y0r, y0i, y1r, y1i;
+    // X0 = s + conj(w1) t (fresh), t <- X2
+    dit_butterfly2_v(sr0, si0, tr0, ti0, w1.x, m1i, x0r, x0i, sr1, si1, tr1, ti1, w1.x, m1i, x1r, x1i);
+    // X1 = d + i conj(w1) u (fresh), u <- X3;  i conj(w1) = (w1.y, w1.x)
+    dit_butterfly2_v(re[a2], im[a2], re[a3], im[a3], w1.y, w1.x, y0r, y0i, re[b2], im[b2], re[b3], im[b3], w1.y,
+                     w1.x, y1r, y1i);
+    re[a0] = x0r; im[a0] = x0i; re[a2] = tr0; im[a2] = ti0; re[a1] = y0r; im[a1] = y0i;     // a3 holds X3
+    re[b0] = x1r; im[b0] = x1i; re[b2] = tr1; im[b2] = ti1; re[b1] = y1r; im[b1] = y1i;
+  });
+}
+
 // ---- step 6: 16 x 16 transpose inside every row of 16 lanes ----------------------------------
 // Row R = lane >> 4 owns 16 tile rows of kRowStride bytes; lane (R, x) stores the f64 of its
 // register with index i at [R][i][x] and then loads row [R][x][0..15].  The padding of 16 bytes
@@ -338,6 +385,7 @@ struct Tables {
 // ---- the twisted transforms of a REAL polynomial (see wave_fft.hpp for the mathematics) ------
 // x[lane + 64 r] in re[r] -> spectrum layout.  The register part w64^r of the twist w4096^n comes
 // from the constant segment (scalar loads), the lane part w4096^lane is folded into T1.
+template <int TWG = WFFT64_TW_GROUP>
 __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[16], double (&im)[16], char* tile,
                                                      const Tables& tb, int lane) {
   static_for<0, 4>([&](auto gc) WFFT_INLINE {
@@ -352,7 +400,7 @@ __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[16], double (&
   fwd16(re, im);
   wave_lds_fence();
   {
-    Pipe16<WFFT64_TW_GROUP, 1, cplx> pipe;
+    Pipe16<TWG, 1, cplx> pipe;
 #ifdef WFFT64_ABLATE_T1
     auto load = [&](auto ic) WFFT_INLINE { return cplx{0.75 + decltype(ic)::value, 0.5}; };
 #else
@@ -393,13 +441,20 @@ __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[16], double (&
 
 // Spectrum C (spectrum layout) -> lo(integral_constant<r>, 1024 c[t]) and, when HI,
 // hi(integral_constant<r>, 1024 c[t + 1024]) for t = lane + 64 r.
-template <bool HI, class Lo, class Hi>
+template <bool HI, int TWG = WFFT64_TW_GROUP, class Lo, class Hi>
 __device__ __forceinline__ void inv1024_twisted_real(double (&re)[16], double (&im)[16], char* tile,
                                                      const Tables& tb, int lane, Lo&& lo, Hi&& hi) {
   inv16(re, im);
   const TileAddr ta = tile_addr(tile, lane);
   row_transpose<false, true>(re, ta);
   row_transpose<false, true>(im, ta);
+#if WFFT64_FUSED_T2
+  {
+    const cplx* t2 = tb.t2 + (lane & 15);
+    const cplx w1 = t2[0], w2 = t2[16];
+    inv_dft4_with_t2(re, im, w1, w2);
+  }
+#else
   {
     const cplx* t2 = tb.t2 + (lane & 15);
     const cplx w1 = t2[0], w2 = t2[16], w3 = t2[32];
@@ -413,10 +468,11 @@ __device__ __forceinline__ void inv1024_twisted_real(double (&re)[16], double (&
     });
   }
   dft4_high_bits<true>(re, im);
+#endif
   exchange_lane_bits(re, im, tile, lane);
   wave_lds_fence();
   {
-    Pipe16<WFFT64_TW_GROUP, 1, cplx> pipe;
+    Pipe16<TWG, 1, cplx> pipe;
 #ifdef WFFT64_ABLATE_T1
     auto load = [&](auto ic) WFFT_INLINE { return cplx{0.75 + decltype(ic)::value, 0.5}; };
 #else
