@@ -127,12 +127,11 @@ int tfhe_hip_synchronize(tfhe_hip_ctx* ctx);
  *          result polynomial) pair of tgsw_extern_mul_to_tlwe (src/tgsw.rs:229-264);
  *          a third of the latency, 4/3 of the arithmetic.
  * AUTO (default): SPLIT while the batch has at most two ciphertexts per compute
- *          unit; above that BATCH64 (the faster throughput form on MI355X for both
- *          parameter sets), which takes the
- *          batch in whole rounds of one ciphertext per wavefront slot; a remainder of
- *          at most two ciphertexts per compute unit runs as SPLIT beside the full
- *          rounds (on a second stream of the context, joined before the call's next
- *          kernel).
+ *          unit, BATCH up to one per SIMD, above that BATCH64 (the fastest throughput
+ *          form on MI355X for both parameter sets), which takes the batch in whole
+ *          rounds of one ciphertext per wavefront slot; a last round that would be at
+ *          most half full runs as SPLIT or BATCH instead, after the full rounds on the
+ *          same stream.
  * Results are identical in every mode. */
 enum { TFHE_HIP_BR_AUTO = 0, TFHE_HIP_BR_BATCH = 1, TFHE_HIP_BR_SPLIT = 2, TFHE_HIP_BR_BATCH64 = 3 };
 int tfhe_hip_set_blind_rotate_mode(tfhe_hip_ctx* ctx, int mode);

@@ -294,13 +294,15 @@ def test_bootstrap_full_size_synthetic_keys(eng, level, B):
         assert (oa[i] == wa).all() and ob[i] == wb and var[i] == wv, i
 
 
-@pytest.mark.parametrize("level,B", [(80, 1030), (128, 1030), (80, 2049), (128, 1100)])
+@pytest.mark.parametrize("level,B", [(80, 700), (80, 2049), (80, 2648), (128, 1030), (128, 2700)])
 def test_blind_rotate_mappings_agree_at_full_size(level, B):
-    """Size-independent property at the bench's parameters: the throughput and
+    """Size-independent property at the bench's parameters: the two throughput mappings and
     the low-latency mapping return the same bits on a batch that spans several
-    rounds of persistent workgroups (and the automatic choice equals both).  In the
-    automatic mode 2 049 gates at l = 2 (rounds of 2 048) and 1 030 / 1 100 at l = 3 (rounds of
-    1 024) leave a remainder that runs in the low-latency mapping on the second stream."""
+    rounds of persistent workgroups (and the automatic choice equals all of them).  The sizes
+    walk the automatic mode's cases on a GPU of 256 compute units: 700 gates run with one
+    wavefront per SIMD, 1 030 in one (half empty) round of two wavefronts per SIMD, and after a
+    full round of 2 048 a remainder of 1 goes to the low-latency mapping, one of 600 or 652 to
+    the one-wavefront-per-SIMD mapping."""
     import tfhe_amd
     P = orc.params(level)
     K = orc.generate_synthetic_keys(P, 90 + level)

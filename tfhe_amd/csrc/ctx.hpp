@@ -23,10 +23,6 @@ struct tfhe_hip_ctx {
   int br_mode = TFHE_HIP_BR_AUTO;
   hipStream_t stream = nullptr;
   bool owns_stream = false;        // created by the library (shards of a multi-GPU context)
-  // second stream for the remainder of a batch beside its full rounds, forked from and joined
-  // to `stream` by the two events
-  hipStream_t aux_stream = nullptr;
-  hipEvent_t fork_event = nullptr, join_event = nullptr;
   std::string err;
   bool have_keys = false;
   tfhe_hip_params P{};

@@ -827,6 +827,7 @@ __global__ __launch_bounds__(64 * kWaves64) void polymul64_kernel(const int32_t*
 
   int prod = blockIdx.x * kWaves64 + wave;
   if (prod < B) fetch(prod, lane0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the first operands have landed
 #pragma unroll 1
   for (; prod < B; prod += stride) {
     auto fresh_lane = [&]() WFFT_INLINE {
@@ -836,7 +837,6 @@ __global__ __launch_bounds__(64 * kWaves64) void polymul64_kernel(const int32_t*
     };
     double re[16], im[16];
     double pre[16], pim[16]; // spectrum of d, waiting while s is transformed
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the operands have landed
     {
       const int lane = fresh_lane();
       const int32_t* in = reinterpret_cast<const int32_t*>(stage) + lane;
@@ -928,6 +928,12 @@ __global__ __launch_bounds__(64 * kWaves64) void polymul64_kernel(const int32_t*
       }
       wfft::wave_lds_fence();
     }
+    // The next product's operands (fetched above) must have landed; this product's stores need
+    // not have.  Memory operations complete in the order issued and at least kStoresAfterFetch
+    // of them were issued after the fetch, so that many may stay in flight (waiting for all of
+    // them exposed the write latency once per product: a tenth of the kernel's time).
+    constexpr int kStoresAfterFetch = MARGIN ? 0 : 8;
+    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kStoresAfterFetch) : "memory");
   }
 }
 
@@ -1140,8 +1146,10 @@ __global__ __launch_bounds__(64 * kWaves64) void blind_rotate64_kernel(BlindRota
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   char* tile = lds + wave * kWave64Bytes;
   char* prev_lds = tile + wfft64::kTileBytes;
-  // persistent workgroups: wavefront slot s takes ciphertexts s, s + slots, ...
-  const int slot = blockIdx.x * kWaves64 + wave;
+  // persistent workgroups: wavefront slot s takes ciphertexts s, s + slots, ...  Slots are numbered
+  // wavefront-major (all workgroups' wavefront 0 first), so that a batch smaller than a full round
+  // spreads over all compute units, one wavefront per SIMD first, instead of filling a few of them.
+  const int slot = wave * gridDim.x + blockIdx.x;
   const int slots = gridDim.x * kWaves64;
   NoMargin no_margin;
 
@@ -2107,7 +2115,7 @@ int launch_blind_rotate_mode(tfhe_hip_ctx* ctx, int mode, hipStream_t stream, co
       else hipLaunchKernelGGL((blind_rotate_split_kernel<3, 7, false, 2>), grid, dim3(192), 0, stream, a);
     }
   } else if (mode == TFHE_HIP_BR_BATCH64) {
-    const unsigned grid = (unsigned)std::min<size_t>((B + kWaves64 - 1) / kWaves64, (size_t)ctx->num_cus);
+    const unsigned grid = (unsigned)std::min<size_t>(B, (size_t)ctx->num_cus);
     const dim3 block(64 * kWaves64);
     if (ctx->P.l == 2) {
       if (hook) hipLaunchKernelGGL((blind_rotate64_kernel<2, 10, true>), dim3(grid), block, 0, stream, a);
@@ -2152,40 +2160,32 @@ int launch_blind_rotate(tfhe_hip_ctx* ctx, const int32_t* bara, const int32_t* b
     return 0;
   }
 #endif
-  // Batches that cannot give every SIMD its own ciphertext run with one workgroup per
-  // ciphertext (2 l wavefronts each, a third of the latency); larger ones with persistent
-  // workgroups, one ciphertext per wavefront, two wavefronts per SIMD (the faster of the two
-  // throughput forms on MI355X for both parameter sets).
+  // Which mapping a batch gets in automatic mode (measured on MI355X, both parameter sets,
+  // tools/time_batch_sizes.py): up to two ciphertexts per compute unit one workgroup per ciphertext
+  // (2 l wavefronts each, a third of the latency); up to one per SIMD the persistent form with one
+  // wavefront per SIMD (a tenth faster than the two-wavefront form running half empty); above
+  // that the persistent form with two wavefronts per SIMD, which takes the batch in rounds of one
+  // ciphertext per wavefront slot.  A last round that would be at most half full costs a whole
+  // round there, so that remainder runs in one of the first two forms instead, after the full
+  // rounds on the same stream.
   const size_t small = 2 * (size_t)ctx->num_cus;
-  int mode = ctx->br_mode;
-  const bool automatic = mode == TFHE_HIP_BR_AUTO;
-  if (automatic)
-    mode = B <= small ? TFHE_HIP_BR_SPLIT : TFHE_HIP_BR_BATCH64;
+  const size_t slots32 = (size_t)ctx->num_cus * kWavesPerBlock, slots64 = (size_t)ctx->num_cus * kWaves64;
   ProfileScope prof(ctx, 1);
-  // A persistent launch takes whole rounds of `slots` ciphertexts: a small remainder would cost
-  // a round of its own.  In automatic mode it goes to the one-workgroup-per-ciphertext mapping
-  // instead, on the context's second stream beside the full rounds (fork and join by events
-  // that exist since tfhe_hip_create: nothing is allocated here).
-  const size_t slots = (size_t)ctx->num_cus * (mode == TFHE_HIP_BR_BATCH64 ? kWaves64 : kWavesPerBlock);
-  const size_t rem = B % slots, full = B - rem;
-  if (automatic && mode != TFHE_HIP_BR_SPLIT && full > 0 && rem > 0 && rem <= small && ctx->aux_stream) {
-    BlindRotateArgs tail = a;
-    tail.bara = bara + full * (size_t)ctx->P.n;
-    if (barb) tail.barb = barb + full;
-    if (acc_io) tail.acc_io = acc_io + full * 3 * kN;
-    if (out_a) tail.out_a = out_a + full * kN;
-    if (out_b) tail.out_b = out_b + full;
-    tail.B = (int32_t)rem;
-    a.B = (int32_t)full;
-    HIP_TRY(ctx, hipEventRecord(ctx->fork_event, ctx->stream));
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->fork_event, 0));
-    if (int rc = launch_blind_rotate_mode(ctx, TFHE_HIP_BR_SPLIT, ctx->aux_stream, tail, rem)) return rc;
-    HIP_TRY(ctx, hipEventRecord(ctx->join_event, ctx->aux_stream));
-    if (int rc = launch_blind_rotate_mode(ctx, mode, ctx->stream, a, full)) return rc;
-    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->join_event, 0));
-    return 0;
-  }
-  return launch_blind_rotate_mode(ctx, mode, ctx->stream, a, B);
+  if (ctx->br_mode != TFHE_HIP_BR_AUTO) return launch_blind_rotate_mode(ctx, ctx->br_mode, ctx->stream, a, B);
+  if (B <= small) return launch_blind_rotate_mode(ctx, TFHE_HIP_BR_SPLIT, ctx->stream, a, B);
+  if (B <= slots32) return launch_blind_rotate_mode(ctx, TFHE_HIP_BR_BATCH, ctx->stream, a, B);
+  const size_t rem = B % slots64, full = B - rem;
+  if (rem == 0 || rem > slots32) return launch_blind_rotate_mode(ctx, TFHE_HIP_BR_BATCH64, ctx->stream, a, B);
+  BlindRotateArgs tail = a;
+  tail.bara = bara + full * (size_t)ctx->P.n;
+  if (barb) tail.barb = barb + full;
+  if (acc_io) tail.acc_io = acc_io + full * 3 * kN;
+  if (out_a) tail.out_a = out_a + full * kN;
+  if (out_b) tail.out_b = out_b + full;
+  tail.B = (int32_t)rem;
+  a.B = (int32_t)full;
+  if (int rc = launch_blind_rotate_mode(ctx, TFHE_HIP_BR_BATCH64, ctx->stream, a, full)) return rc;
+  return launch_blind_rotate_mode(ctx, rem <= small ? TFHE_HIP_BR_SPLIT : TFHE_HIP_BR_BATCH, ctx->stream, tail, rem);
 }
 
 int launch_keyswitch(tfhe_hip_ctx* ctx, const int32_t* in_a, const int32_t* in_b, const int32_t* in2_a,
@@ -2392,13 +2392,6 @@ int tfhe_hip_create(tfhe_hip_ctx** out, int device) {
     tfhe_hip_destroy(ctx);
     return TFHE_HIP_ERR_RUNTIME;
   }
-  // second stream and the two events of the fork / join around a batch's remainder
-  if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->join_event, hipEventDisableTiming) != hipSuccess) {
-    tfhe_hip_destroy(ctx);
-    return TFHE_HIP_ERR_RUNTIME;
-  }
   std::vector<cplx> t64;
   make_tables64(t64);
   double w64[32];
@@ -2437,12 +2430,6 @@ void tfhe_hip_destroy(tfhe_hip_ctx* ctx) {
   if (ctx->tables) (void)hipFree(ctx->tables);
   if (ctx->tables64) (void)hipFree(ctx->tables64);
   if (ctx->prev_ws) (void)hipFree(ctx->prev_ws);
-  if (ctx->aux_stream) {
-    (void)hipStreamSynchronize(ctx->aux_stream);
-    (void)hipStreamDestroy(ctx->aux_stream);
-  }
-  if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
-  if (ctx->join_event) (void)hipEventDestroy(ctx->join_event);
   if (ctx->bkfft) (void)hipFree(ctx->bkfft);
   if (ctx->ksblob) (void)hipFree(ctx->ksblob);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
