@@ -29,7 +29,6 @@ struct tfhe_hip_ctx {
   int row_stride = 0;
   wfft::cplx* tables = nullptr;  // device: tE[1024], twist[1024]
   wfft::cplx* tables64 = nullptr;  // device: the tables of wave_fft64.hpp
-  int32_t* prev_ws = nullptr;      // textbook build: blind_rotate_textbook_kernel's accumulators, one slot per wavefront
   wfft::cplx* bkfft = nullptr;   // device blob 1
   char* ksblob = nullptr;        // device blob 2: rows then variances
   size_t bk_bytes = 0, ks_bytes = 0, ks_rows_bytes = 0;

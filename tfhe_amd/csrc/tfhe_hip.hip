@@ -437,7 +437,6 @@ struct BlindRotateArgs {
   const cplx* bkfft;        // [n][l][2][32][64]
   const cplx* tables;       // make_tables: two pairs of 1024-entry tables
   const cplx* tables64;     // make_tables64
-  int32_t* prev_ws;         // textbook build: [wavefront slots][2][N] accumulators of blind_rotate_textbook_kernel
   int32_t* acc_io;          // hook mode: [B][3][N] accumulators, updated in place
   int32_t* out_a;           // bootstrap mode: [B][N] extracted mask
   int32_t* out_b;           // bootstrap mode: [B]
@@ -1251,11 +1250,13 @@ __device__ __forceinline__ int32_t round_wrap_i32(double x) {
   return (int32_t)(uint32_t)(unsigned long long)__double_as_longlong(x + 6755399441055744.0);
 }
 
-// Two wavefronts per SIMD, as blind_rotate64_kernel (same LDS share: exchange tile + the
-// sample being decomposed as lane-private granules).  The two result spectra take 128 of a
-// wavefront's 256 registers, so the accumulator itself (touched at the start and at the end of
-// an iteration only) lives in the per-wavefront workspace in global memory, as lane-private
-// 16-byte granules ((h, g) at [(4 h + g) * 64 + lane]).
+// Two wavefronts per SIMD, as blind_rotate64_kernel, and the same split of a wavefront's state:
+// the two result spectra take 128 of its 256 registers, the sample being decomposed (with the
+// offset added and the top bit of every digit field flipped, so that digit p is a sign-extended bit
+// field) is packed into 20 - 22 more (PackedSample), and the accumulator, touched at both ends of an
+// iteration only, lives in 8 KiB of the wavefront's LDS share as lane-private 16-byte granules
+// ((h, g) at [(4 h + g) * 64 + lane]); the rotation stages it there in coefficient order for its
+// gather.  Global memory is read for the key and written for the result.
 typedef int tb_int4 __attribute__((ext_vector_type(4)));
 
 template <int L, int BGBIT>
@@ -1265,27 +1266,28 @@ __global__ __launch_bounds__(64 * kWaves64) void blind_rotate_textbook_kernel(Bl
   const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   char* tile = lds + wave * kWave64Bytes;
-  char* tt_lds = tile + wfft64::kTileBytes;
-  const int slot = blockIdx.x * kWaves64 + wave, slots = gridDim.x * kWaves64;
-  volatile tb_int4* acc_ws = reinterpret_cast<volatile tb_int4*>(args.prev_ws + (size_t)slot * 2 * kN) + lane0;
+  char* acc_lds = tile + wfft64::kTileBytes;
+  const int slot = wave * gridDim.x + blockIdx.x, slots = gridDim.x * kWaves64;      // as blind_rotate64_kernel
 
 #pragma unroll 1
   for (int b = slot; b < args.B; b += slots) {
     {
       // acc = trivial(X^(2N - barb) [mu]*N), src/bootstrapping.rs:89-96: polynomial 0 (mask) = 0,
       // polynomial 1 (body) = the rotated test vector
+      tb_int4* acc_g = reinterpret_cast<tb_int4*>(acc_lds) + lane0;
       const int w0 = (2 * kN - args.barb[b]) & (2 * kN - 1);
       const bool flip = w0 >= kN;
       const int w = flip ? w0 - kN : w0;
+      wfft::wave_lds_fence();
       static_for<0, 4>([&](auto gc) WFFT_INLINE {
         constexpr int g = decltype(gc)::value;
-        acc_ws[g * 64] = tb_int4{0, 0, 0, 0};
+        acc_g[g * 64] = tb_int4{0, 0, 0, 0};
         tb_int4 v;
         v.x = ((lane0 + 64 * (4 * g + 0) < w) != flip) ? wneg(args.mu) : args.mu;
         v.y = ((lane0 + 64 * (4 * g + 1) < w) != flip) ? wneg(args.mu) : args.mu;
         v.z = ((lane0 + 64 * (4 * g + 2) < w) != flip) ? wneg(args.mu) : args.mu;
         v.w = ((lane0 + 64 * (4 * g + 3) < w) != flip) ? wneg(args.mu) : args.mu;
-        acc_ws[(4 + g) * 64] = v;
+        acc_g[(4 + g) * 64] = v;
       });
     }
     const int32_t* bara = args.bara + (size_t)b * args.n;
@@ -1300,16 +1302,19 @@ __global__ __launch_bounds__(64 * kWaves64) void blind_rotate_textbook_kernel(Bl
       if (abar == 0) continue;
       int lane = lane0;
       asm volatile("" : "+v"(lane));
+      tb_int4* acc_g = reinterpret_cast<tb_int4*>(acc_lds) + lane;
       // t = X^abar acc - acc with the decomposition offset added and the top bit of every digit
-      // field flipped (digit p is then a sign-extended bit field), to LDS
+      // field flipped, packed into registers
+      PackedSample<L, BGBIT> tt;
       {
         int32_t acc[2][16], v[2][16];
+        wfft::wave_lds_fence();
         static_for<0, 8>([&](auto ic) WFFT_INLINE {
           constexpr int h = decltype(ic)::value >> 2, g = decltype(ic)::value & 3;
-          const tb_int4 x = acc_ws[(4 * h + g) * 64];
+          const tb_int4 x = acc_g[(4 * h + g) * 64];
           acc[h][4 * g] = x.x; acc[h][4 * g + 1] = x.y; acc[h][4 * g + 2] = x.z; acc[h][4 * g + 3] = x.w;
         });
-        int32_t* S = reinterpret_cast<int32_t*>(tile);
+        int32_t* S = reinterpret_cast<int32_t*>(acc_lds);
         wfft::wave_lds_fence();
         static_for<0, 32>([&](auto ic) WFFT_INLINE {
           constexpr int h = decltype(ic)::value >> 4, r = decltype(ic)::value & 15;
@@ -1323,16 +1328,21 @@ __global__ __launch_bounds__(64 * kWaves64) void blind_rotate_textbook_kernel(Bl
           v[h][r] = S[h * kN + ((lane + 64 * r - w) & (kN - 1))];
         });
         wfft::wave_lds_fence();
-        static_for<0, 32>([&](auto ic) WFFT_INLINE {
-          constexpr int h = decltype(ic)::value >> 4, r = decltype(ic)::value & 15;
-          const bool neg = (lane + 64 * r < w) != flip;
-          const int32_t x = neg ? wneg(v[h][r]) : v[h][r];
-          v[h][r] = (int32_t)(((uint32_t)wsub(x, acc[h][r]) + tb_offset<L, BGBIT>()) ^ tb_field_tops<L, BGBIT>());
-        });
-        tb_int4* tt = reinterpret_cast<tb_int4*>(tt_lds) + lane;
-        static_for<0, 8>([&](auto ic) WFFT_INLINE {
+        static_for<0, 8>([&](auto ic) WFFT_INLINE {                  // the accumulator back as granules
           constexpr int h = decltype(ic)::value >> 2, g = decltype(ic)::value & 3;
-          tt[(4 * h + g) * 64] = tb_int4{v[h][4 * g], v[h][4 * g + 1], v[h][4 * g + 2], v[h][4 * g + 3]};
+          acc_g[(4 * h + g) * 64] = tb_int4{acc[h][4 * g], acc[h][4 * g + 1], acc[h][4 * g + 2], acc[h][4 * g + 3]};
+        });
+        wfft::wave_lds_fence();
+        static_for<0, 16>([&](auto rc) WFFT_INLINE {
+          constexpr int r = decltype(rc)::value;
+          uint32_t x[2];
+          static_for<0, 2>([&](auto hc) WFFT_INLINE {
+            constexpr int h = decltype(hc)::value;
+            const bool neg = (lane + 64 * r < w) != flip;
+            const int32_t y = neg ? wneg(v[h][r]) : v[h][r];
+            x[h] = ((uint32_t)wsub(y, acc[h][r]) + tb_offset<L, BGBIT>()) ^ tb_field_tops<L, BGBIT>();
+          });
+          tt.template put<r>(x[0], x[1]);
         });
       }
       // spectra of the two result polynomials, summed over the (k+1) l rows
@@ -1343,32 +1353,29 @@ __global__ __launch_bounds__(64 * kWaves64) void blind_rotate_textbook_kernel(Bl
       });
       const cplx* bk_i = args.bkfft + (size_t)i * L * 4 * 1024 + lane;
 #pragma unroll 1
-      for (int row = 0; row < 2 * L; row++) {            // row = 2 p + j: level p, component j
-        const int decal = 32 - ((row >> 1) + 1) * BGBIT;
-        const tb_int4* tt = reinterpret_cast<const tb_int4*>(tt_lds) + lane + (row & 1) * 4 * 64;
-        double re[16], im[16];
-        wfft::wave_lds_fence();
-        static_for<0, 4>([&](auto gc) WFFT_INLINE {
-          constexpr int g = decltype(gc)::value;
-          const tb_int4 t = tt[g * 64];
-          re[4 * g + 0] = (double)(int32_t)__builtin_amdgcn_sbfe(t.x, decal, BGBIT);
-          re[4 * g + 1] = (double)(int32_t)__builtin_amdgcn_sbfe(t.y, decal, BGBIT);
-          re[4 * g + 2] = (double)(int32_t)__builtin_amdgcn_sbfe(t.z, decal, BGBIT);
-          re[4 * g + 3] = (double)(int32_t)__builtin_amdgcn_sbfe(t.w, decal, BGBIT);
-        });
-        wfft64::fwd1024_twisted_real(re, im, tile, tb, lane);
-        const cplx* krow = bk_i + (size_t)row * 2 * 1024;
-        static_for<0, 2>([&](auto uc) WFFT_INLINE {
-          constexpr int u = decltype(uc)::value;
-          auto load_k = [&](auto ic) WFFT_INLINE { return krow[u * 1024 + decltype(ic)::value * 64]; };
-          wfft64::Pipe16<4, TFHE_K64_DEPTH, cplx> kp;
-          kp.prologue(load_k);
-          kp.run2(load_k, [&](auto i0, const cplx& k0, auto i1, const cplx& k1) WFFT_INLINE {
-            constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;
-            ur[u][s0] += re[s0] * k0.x - im[s0] * k0.y;
-            ui[u][s0] += re[s0] * k0.y + im[s0] * k0.x;
-            ur[u][s1] += re[s1] * k1.x - im[s1] * k1.y;
-            ui[u][s1] += re[s1] * k1.y + im[s1] * k1.x;
+      for (int p = 0; p < L; p++) {
+        const int decal = 32 - (p + 1) * BGBIT;
+        static_for<0, 2>([&](auto jc) WFFT_INLINE {                   // row = 2 p + j: level p, component j
+          constexpr int j = decltype(jc)::value;
+          double re[16], im[16];
+          static_for<0, 16>([&](auto rc) WFFT_INLINE {
+            constexpr int r = decltype(rc)::value;
+            re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(tt.template get<j, r>(), decal, BGBIT);
+          });
+          wfft64::fwd1024_twisted_real(re, im, tile, tb, lane);
+          const cplx* krow = bk_i + (size_t)(2 * p + j) * 2 * 1024;
+          static_for<0, 2>([&](auto uc) WFFT_INLINE {
+            constexpr int u = decltype(uc)::value;
+            auto load_k = [&](auto ic) WFFT_INLINE { return krow[u * 1024 + decltype(ic)::value * 64]; };
+            wfft64::Pipe16<4, TFHE_K64_DEPTH, cplx> kp;
+            kp.prologue(load_k);
+            kp.run2(load_k, [&](auto i0, const cplx& k0, auto i1, const cplx& k1) WFFT_INLINE {
+              constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;
+              ur[u][s0] += re[s0] * k0.x - im[s0] * k0.y;
+              ui[u][s0] += re[s0] * k0.y + im[s0] * k0.x;
+              ur[u][s1] += re[s1] * k1.x - im[s1] * k1.y;
+              ui[u][s1] += re[s1] * k1.y + im[s1] * k1.x;
+            });
           });
         });
       }
@@ -1379,22 +1386,26 @@ __global__ __launch_bounds__(64 * kWaves64) void blind_rotate_textbook_kernel(Bl
             ur[u], ui[u], tile, tb, lane, [&](auto rc, double v) WFFT_INLINE { lo_v[decltype(rc)::value] = v; },
             [&](auto rc, double v) WFFT_INLINE { ui[u][decltype(rc)::value] = v; });
         // negacyclic product = low half - high half of the convolution; acc[u] += it, modulo 2^32
+        wfft::wave_lds_fence();
         static_for<0, 4>([&](auto gc) WFFT_INLINE {
           constexpr int g = decltype(gc)::value;
-          tb_int4 x = acc_ws[(4 * u + g) * 64];
+          tb_int4 x = acc_g[(4 * u + g) * 64];
           x.x = wadd(x.x, round_wrap_i32(lo_v[4 * g + 0] - ui[u][4 * g + 0]));
           x.y = wadd(x.y, round_wrap_i32(lo_v[4 * g + 1] - ui[u][4 * g + 1]));
           x.z = wadd(x.z, round_wrap_i32(lo_v[4 * g + 2] - ui[u][4 * g + 2]));
           x.w = wadd(x.w, round_wrap_i32(lo_v[4 * g + 3] - ui[u][4 * g + 3]));
-          acc_ws[(4 * u + g) * 64] = x;
+          acc_g[(4 * u + g) * 64] = x;
         });
+        wfft::wave_lds_fence();
       });
     }
     // extract_lwe, src/tlwe.rs:159-180 (k = 1): a[0] = acc0[0], a[j] = -acc0[N-j], b = body[0]
+    const tb_int4* acc_g = reinterpret_cast<const tb_int4*>(acc_lds) + lane0;
     int32_t* oa = args.out_a + (size_t)b * kN;
+    wfft::wave_lds_fence();
     static_for<0, 4>([&](auto gc) WFFT_INLINE {
       constexpr int g = decltype(gc)::value;
-      const tb_int4 x = acc_ws[g * 64];
+      const tb_int4 x = acc_g[g * 64];
       const int32_t c[4] = {x.x, x.y, x.z, x.w};
       static_for<0, 4>([&](auto ec) WFFT_INLINE {
         constexpr int r = 4 * g + decltype(ec)::value;
@@ -1403,8 +1414,9 @@ __global__ __launch_bounds__(64 * kWaves64) void blind_rotate_textbook_kernel(Bl
         else oa[kN - t] = wneg(c[decltype(ec)::value]);
       });
     });
-    const tb_int4 body0 = acc_ws[4 * 64];
+    const tb_int4 body0 = acc_g[4 * 64];
     if (lane0 == 0) args.out_b[b] = body0.x;
+    wfft::wave_lds_fence();
   }
 }
 
@@ -2006,10 +2018,6 @@ int alloc_keys(tfhe_hip_ctx* ctx, const tfhe_hip_params* p) {
   blob_sizes(p, &ctx->bk_bytes, &ctx->ks_bytes, &ctx->ks_rows_bytes);
   HIP_TRY(ctx, hipMalloc((void**)&ctx->bkfft, ctx->bk_bytes));
   HIP_TRY(ctx, hipMalloc((void**)&ctx->ksblob, ctx->ks_bytes));
-#ifdef TFHE_TEXTBOOK
-  if (!ctx->prev_ws)       // one slot per wavefront of a full blind_rotate_textbook_kernel launch
-    HIP_TRY(ctx, hipMalloc((void**)&ctx->prev_ws, (size_t)ctx->num_cus * kWaves64 * 2 * kN * sizeof(int32_t)));
-#endif
   return 0;
 }
 
@@ -2144,14 +2152,13 @@ int launch_blind_rotate(tfhe_hip_ctx* ctx, const int32_t* bara, const int32_t* b
   BlindRotateArgs a;
   a.bara = bara; a.barb = barb; a.bkfft = ctx->bkfft; a.tables = ctx->tables;
   a.tables64 = ctx->tables64;
-  a.prev_ws = ctx->prev_ws;
   a.acc_io = acc_io; a.out_a = out_a; a.out_b = out_b; a.mu = mu; a.n = ctx->P.n; a.B = (int32_t)B;
 #ifdef TFHE_TEXTBOOK
   {
     // the textbook build has one mapping: one ciphertext per wavefront, two wavefronts per SIMD
     if (acc_io) return fail(ctx, TFHE_HIP_ERR_ARG, "the blind-rotate hook is not part of the textbook build");
     ProfileScope prof(ctx, 1);
-    const unsigned grid = (unsigned)std::min<size_t>((B + kTbWaves - 1) / kTbWaves, (size_t)ctx->num_cus);
+    const unsigned grid = (unsigned)std::min<size_t>(B, (size_t)ctx->num_cus);      // wavefront-major slots
     if (ctx->P.l == 2)
       hipLaunchKernelGGL((blind_rotate_textbook_kernel<2, 10>), dim3(grid), dim3(64 * kTbWaves), 0, ctx->stream, a);
     else
@@ -2429,7 +2436,6 @@ void tfhe_hip_destroy(tfhe_hip_ctx* ctx) {
   tfhe_detail::release_handles(ctx);
   if (ctx->tables) (void)hipFree(ctx->tables);
   if (ctx->tables64) (void)hipFree(ctx->tables64);
-  if (ctx->prev_ws) (void)hipFree(ctx->prev_ws);
   if (ctx->bkfft) (void)hipFree(ctx->bkfft);
   if (ctx->ksblob) (void)hipFree(ctx->ksblob);
   if (ctx->scratch) (void)hipFree(ctx->scratch);

@@ -21,8 +21,19 @@ specs = [a.split("=", 1) for a in args]
 
 def build(spec):
     n, flags = spec
-    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-c", "--offload-arch=gfx950", "-mllvm",
-           "-amdgpu-sched-strategy=max-ilp"] + flags.split()
+    # "@sched=<strategy>" among the flags replaces the default scheduling strategy (max-ilp);
+    # "@sched=default" drops the option
+    sched = "max-ilp"
+    rest = []
+    for f in flags.split():
+        if f.startswith("@sched="):
+            sched = f[7:]
+        else:
+            rest.append(f)
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-c", "--offload-arch=gfx950"]
+    if sched != "default":
+        cmd += ["-mllvm", "-amdgpu-sched-strategy=" + sched]
+    cmd += rest
     obj = os.path.join(OUT, n + ".o")
     r = subprocess.run(cmd + ["-Rpass-analysis=kernel-resource-usage", "-o", obj,
                               os.path.join(ROOT, "tfhe_amd/csrc/tfhe_hip.hip")], capture_output=True, text=True)
