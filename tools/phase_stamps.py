@@ -4,7 +4,10 @@ Needs a library built with -DTFHE_STAMPS (diagnostic build, never the shipped on
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c -mllvm -amdgpu-sched-strategy=max-ilp \
         -DTFHE_STAMPS -o /tmp/stamps.o tfhe_amd/csrc/tfhe_hip.hip
   hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libstamps.so /tmp/stamps.o tfhe_amd/csrc/host_api.o -ldl -lpthread
-  TFHE_HIP_LIB=/tmp/libstamps.so python tools/phase_stamps.py [batch|split|polymul]
+  TFHE_HIP_LIB=/tmp/libstamps.so python tools/phase_stamps.py [batch|split]
+Instrumented: blind_rotate_kernel (mode batch) and blind_rotate_split_kernel (mode split); the
+kernels with two wavefronts per SIMD are not (two interleaved wavefronts make per-phase shares
+meaningless; tools/sweep_variants.py with the ablation macros is the tool for them).
 The stamps are not scheduling barriers: instructions move across them, so the shares of
 neighbouring phases are indicative only (workgroup barriers, as in the split kernel, pin them).
 """
@@ -39,16 +42,7 @@ def show(names, st, per):
     print(f"  total {tot / per:.0f} ticks per unit")
 
 
-if which == "polymul":
-    B = 65536
-    d, s = rnd((B, 1024), -512, 512), rnd((B, 1024))
-    out = torch.empty((B, 2047), dtype=torch.int32, device=dev)
-    for _ in range(2):
-        eng.polymul_dev(d, s, out)
-    print("polymul_kernel, per pair of products (32 pairs per wavefront)")
-    show({0: "loop top", 1: "wait for operands", 2: "convert d", 3: "forward d", 4: "park, convert s, next fetch",
-          5: "forward s", 7: "pointwise", 9: "inverse, untwist", 10: "round, store"}, stamps(), 32)
-else:
+if True:
     lv = LEVELS[80]
     params = tfhe_amd.make_params(lv["n"], l=lv["l"], bg_bit=lv["bg_bit"])
     K = synthetic_keys(80, 5)
