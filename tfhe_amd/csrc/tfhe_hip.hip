@@ -1569,7 +1569,12 @@ __global__ __launch_bounds__(kKsBlock) void keyswitch_kernel(
 // three rows of the non-zero digits are loaded and each ciphertext subtracts the
 // one its digit selects; the digit is wave-uniform, so the selection is a scalar
 // branch.  Thread layout and the order of the variance sum as in keyswitch_kernel.
-constexpr int kKsTile = 8;
+// ciphertexts per workgroup; 16 and 32 halve and quarter the L2 reads but the compiler then keeps
+// the partial sums in scratch memory (256 registers + 428 / 1 616 bytes per lane)
+#ifndef TFHE_KS_TILE
+#define TFHE_KS_TILE 8
+#endif
+constexpr int kKsTile = TFHE_KS_TILE;
 
 template <int TC>   // TC = ks_t when known at compile time, 0 = run-time t_rt
 __global__ __launch_bounds__(kKsBlock) void keyswitch_tile_kernel(
