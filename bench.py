@@ -434,7 +434,7 @@ def time_nand(eng, torch, dist, dev, world, rank, level, K, B, steps, warmup, ch
               total=None):
     """Times `steps` batches of B NAND gates on the loaded keys (each batch in launches of at
     most `chunk` gates); returns the measurements of this rank (max over ranks for the elapsed
-    time) and checks one timed output.  total: gates of all ranks per step (default B * world)."""
+    time) and checks three timed outputs (first, a third in, last) against the oracle.  total: gates of all ranks per step (default B * world)."""
     chunk = chunk or B
     lv = LEVELS[level]
     n = lv["n"]
@@ -509,8 +509,9 @@ def time_nand(eng, torch, dist, dev, world, rank, level, K, B, steps, warmup, ch
     }
     if check and rank == 0 and K is not None:
         # the outputs of the last timed step: one gate against the CPU oracle
-        res["output_check"] = {"gate_index": B // 3, "matches_oracle": oracle_check(
-            level, K, ca_a, ca_b, cb_a, cb_b, out_a, out_b, B // 3)}
+        idx = sorted({0, B // 3, B - 1})
+        res["output_check"] = {"gate_indices": idx, "matches_oracle": all(
+            oracle_check(level, K, ca_a, ca_b, cb_a, cb_b, out_a, out_b, i) for i in idx)}
     return res, (ca_a, ca_b, cb_a, cb_b, out_a, out_b)
 
 

@@ -193,6 +193,44 @@ def test_keyswitch_large_batch(n, ks_t):
         assert (ma[i] == wa).all() and mb[i] == wb and mv[i] == wv, i
 
 
+@pytest.mark.parametrize("n", [20, 630])
+def test_keyswitch_largest_batches(n):
+    """From 64 ciphertexts per compute unit on (t = 8) the key switch runs in its 32-ciphertext form,
+    every wavefront selecting the key rows through an LDS area of its own.  A ragged batch of that
+    size must equal the same inputs switched in chunks that take the other kernels, and the
+    oracle; so must the mux form (two inputs and the constant)."""
+    import tfhe_amd
+    P = orc.small_params(n=n)
+    P.l, P.bg_bit = 2, 10
+    K = orc.generate_synthetic_keys(P, 150 + n)
+    B = 16384 + 37
+    a = orc.uniform_i32(151, (B, 1024))
+    b = orc.uniform_i32(152, (B,))
+    a[7, :] = 0
+    a[B - 1, :] = -1
+    e = tfhe_amd.Engine(0)
+    try:
+        e.load_keys(_hip_params(P), K["bk"], K["ks_a"], K["ks_b"], K["ks_var"])
+        oa, ob, var = e.keyswitch(a, b, want_var=True)
+        for lo in (0, 2051, 9000, B - 1500):
+            ca, cb, cv = e.keyswitch(a[lo:lo + 1500], b[lo:lo + 1500], want_var=True)
+            assert (oa[lo:lo + 1500] == ca).all() and (ob[lo:lo + 1500] == cb).all() and (var[lo:lo + 1500] == cv).all()
+        if n == 20:
+            ca = (orc.uniform_i32(153, (B, P.n)), orc.uniform_i32(154, (B,)))
+            cb = (orc.uniform_i32(155, (B, P.n)), orc.uniform_i32(156, (B,)))
+            cc = (orc.uniform_i32(157, (B, P.n)), orc.uniform_i32(158, (B,)))
+            ma, mb, mv = e.gate("mux", ca, cb, cc, want_var=True)
+    finally:
+        e.close()
+    for i in (0, 7, 31, 32, 16383, 16384, B - 1):
+        wa, wb, wv = orc.key_switch(P, K["ks_a"], K["ks_b"], a[i], b[i], K["ks_var"])
+        assert (oa[i] == wa).all() and ob[i] == wb and var[i] == wv, i
+        if n == 20:
+            wa, wb, wv = orc.gate(P, "mux", K, (ca[0][i], ca[1][i], 0.0), (cb[0][i], cb[1][i], 0.0),
+                                  (cc[0][i], cc[1][i], 0.0), orc.MUL_EXACT)
+            assert (ma[i] == wa).all() and mb[i] == wb and mv[i] == wv, i
+
+
 @pytest.mark.parametrize("tag", ["l2", "l3"])
 def test_gates_small_n(eng, tag):
     l, bg = SHAPES[tag]

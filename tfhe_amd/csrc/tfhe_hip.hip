@@ -1575,6 +1575,10 @@ __global__ __launch_bounds__(kKsBlock) void keyswitch_kernel(
 #define TFHE_KS_TILE 8
 #endif
 constexpr int kKsTile = TFHE_KS_TILE;
+#ifndef TFHE_KS_LDS_TILE
+#define TFHE_KS_LDS_TILE 32
+#endif
+constexpr int kKsLdsTile = TFHE_KS_LDS_TILE;       // keyswitch_lds_kernel
 
 template <int TC>   // TC = ks_t when known at compile time, 0 = run-time t_rt
 __global__ __launch_bounds__(kKsBlock) void keyswitch_tile_kernel(
@@ -1665,6 +1669,134 @@ __global__ __launch_bounds__(kKsBlock) void keyswitch_tile_kernel(
       const double* vi = ks_var + (size_t)i * T * 4;
 #pragma unroll
       for (int j = 0; j < T; j++) var += vi[j * 4 + ((aibar >> (32 - (j + 1) * 2)) & 3)];
+    }
+    var_out[b0 + cv] = var;
+  }
+}
+
+// lwe_key_switch for the largest batches (t = 8, the crate's value): a workgroup takes TILE
+// ciphertexts, so a key row is fetched from L2 once per TILE ciphertexts (keyswitch_tile_kernel is
+// bound by exactly those reads).  Selecting one of a position's rows per ciphertext by scalar
+// branches, as keyswitch_tile_kernel does, does not scale to such tiles (the compiler runs out of
+// scalar registers and keeps the sums in scratch memory); here every wavefront keeps the
+// position's four 16-byte slices per lane (digit 0: zeros) in a 4 KiB LDS area of its own and
+// every ciphertext reads back the slice its digit selects: one scalar bit-field extract, one
+// address add, one ds_read_b128 and four subtractions per (ciphertext, position), no branch.
+// A wavefront's LDS operations execute in order and the area is private to it, so the next
+// position's slices can be stored without any wait.  The digits of the tile (16 bits per
+// coefficient: t = 8 digits of 2 bits) are staged in LDS.  Thread layout, partial sums and the
+// order of the variance sum as in keyswitch_kernel.
+template <int TILE>
+__global__ __launch_bounds__(kKsBlock) void keyswitch_lds_kernel(
+    const int32_t* __restrict__ in_a, const int32_t* __restrict__ in_b,
+    const int32_t* __restrict__ in2_a, const int32_t* __restrict__ in2_b, int32_t c_b,
+    int in_stride, const int32_t* __restrict__ ks_rows, const double* __restrict__ ks_var,
+    int row_stride, int n, int n_ks, int B, int32_t* __restrict__ out_a,
+    int32_t* __restrict__ out_b, double* __restrict__ var_out) {
+  constexpr int T = 8;
+  static_assert(TILE >= 8 && TILE <= 64 && (TILE & (TILE - 1)) == 0, "one lane per ciphertext of the tile reads its digits");
+  __shared__ uint16_t digits[TILE][kN];                          // top 16 bits of a_i + offset
+  __shared__ int4 rows_s[kKsBlock / 64][4][64];                  // per wavefront: digit, lane; reused for the partial sums
+  const int b0 = blockIdx.x * TILE;
+  const int nvec = row_stride / 4;
+  const int tpg = (nvec + 63) / 64 * 64;      // whole wavefronts per group: the digits stay wave-uniform
+  const int G = kKsBlock / tpg;
+  const int g = threadIdx.x / tpg, v = threadIdx.x - g * tpg;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int32_t prec_offset = 1 << (32 - (1 + 2 * T));
+  for (int c = 0; c < TILE; c++) {
+    const int b = b0 + c;
+    for (int i = threadIdx.x; i < n_ks; i += kKsBlock) {
+      uint32_t x = 0;                                 // all digits 0: nothing is subtracted
+      if (b < B) {
+        int32_t ai = in_a[(size_t)b * in_stride + i];
+        if (in2_a) ai = wadd(ai, in2_a[(size_t)b * in_stride + i]);
+        x = (uint32_t)wadd(ai, prec_offset);
+      }
+      digits[c][i] = (uint16_t)(x >> 16);
+    }
+  }
+  rows_s[wave][0][lane] = make_int4(0, 0, 0, 0);
+  __syncthreads();
+  uint32_t acc[TILE][4];
+#pragma unroll
+  for (int c = 0; c < TILE; c++) acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0;
+  if (g < G) {
+    // whole wavefronts enter (g is wave-uniform); lanes beyond the row work on a copy of its last
+    // slice, so that every lane is active when the digits are read across lanes below
+    const int32_t* col = ks_rows + 4 * min(v, nvec - 1);
+    int4* mine = &rows_s[wave][0][lane];                          // + 64 d: the slice of digit d
+    for (int i = g; i < n_ks; i += G) {
+      // lane c holds the 16 digit bits of ciphertext c; they become scalars one by one below
+      const uint32_t dv = digits[lane & (TILE - 1)][i];
+      const int32_t* r = col + (size_t)i * T * 4 * row_stride;
+      int4 r1 = *reinterpret_cast<const int4*>(r + row_stride);
+      int4 r2 = *reinterpret_cast<const int4*>(r + 2 * row_stride);
+      int4 r3 = *reinterpret_cast<const int4*>(r + 3 * row_stride);
+#pragma unroll 1
+      for (int j = 0; j < T; j++) {
+        mine[64] = r1;
+        mine[128] = r2;
+        mine[192] = r3;
+        if (j + 1 < T) {
+          const int32_t* rn = r + (size_t)(j + 1) * 4 * row_stride;
+          r1 = *reinterpret_cast<const int4*>(rn + row_stride);
+          r2 = *reinterpret_cast<const int4*>(rn + 2 * row_stride);
+          r3 = *reinterpret_cast<const int4*>(rn + 3 * row_stride);
+        }
+        const int sh = 16 - (j + 1) * 2;
+        // eight slices in flight at a time: all of them at once would take the registers of the sums
+#pragma unroll
+        for (int c0 = 0; c0 < TILE; c0 += 8) {
+          int4 row[8];
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            const uint32_t d = ((uint32_t)__builtin_amdgcn_readlane((int)dv, c0 + e) >> sh) & 3u;      // uniform
+            row[e] = mine[64 * d];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            acc[c0 + e][0] -= (uint32_t)row[e].x; acc[c0 + e][1] -= (uint32_t)row[e].y;
+            acc[c0 + e][2] -= (uint32_t)row[e].z; acc[c0 + e][3] -= (uint32_t)row[e].w;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  int4* part = &rows_s[0][0][0];                                   // kKsBlock entries are there
+#pragma unroll
+  for (int c = 0; c < TILE; c++) {
+    const int b = b0 + c;
+    __syncthreads();
+    part[threadIdx.x] = make_int4((int)acc[c][0], (int)acc[c][1], (int)acc[c][2], (int)acc[c][3]);
+    __syncthreads();
+    if (b < B && g == 0 && v < nvec) {
+      uint32_t a4[4] = {acc[c][0], acc[c][1], acc[c][2], acc[c][3]};
+      for (int k = 1; k < G; k++) {
+        const int4 o = part[k * tpg + v];
+        a4[0] += (uint32_t)o.x; a4[1] += (uint32_t)o.y; a4[2] += (uint32_t)o.z; a4[3] += (uint32_t)o.w;
+      }
+      for (int e = 0; e < 4; e++) {
+        const int x = 4 * v + e;
+        if (x < n) out_a[(size_t)b * n + x] = (int32_t)a4[e];
+        else if (x == n) {
+          int32_t bb = in_b[b];
+          if (in2_b) bb = wadd(wadd(c_b, bb), in2_b[b]);
+          out_b[b] = wadd(bb, (int32_t)a4[e]);
+        }
+      }
+    }
+  }
+  // variances: thread kKsBlock-1-c sums ciphertext c in the reference's order (lwe.rs:109)
+  const int cv = kKsBlock - 1 - (int)threadIdx.x;
+  if (var_out && cv >= 0 && cv < TILE && b0 + cv < B) {
+    double var = 0.0;
+    for (int i = 0; i < n_ks; i++) {
+      const uint32_t dg = digits[cv][i];
+      const double* vi = ks_var + (size_t)i * T * 4;
+#pragma unroll
+      for (int j = 0; j < T; j++) var += vi[j * 4 + ((dg >> (16 - (j + 1) * 2)) & 3)];
     }
     var_out[b0 + cv] = var;
   }
@@ -2205,7 +2337,13 @@ int launch_keyswitch(tfhe_hip_ctx* ctx, const int32_t* in_a, const int32_t* in_b
                      double* var_out, size_t B) {
   const double* ks_var = (const double*)(ctx->ksblob + ctx->ks_rows_bytes);
   ProfileScope prof(ctx, 2);
-  if (B >= (size_t)ctx->num_cus * kKsTile) {
+  if (ctx->P.ks_t == 8 && B >= (size_t)ctx->num_cus * 2 * kKsLdsTile) {
+    // two tiles of the large form per compute unit and more: a quarter of the key reads
+    const unsigned grid = (unsigned)((B + kKsLdsTile - 1) / kKsLdsTile);
+    hipLaunchKernelGGL(keyswitch_lds_kernel<kKsLdsTile>, dim3(grid), dim3(kKsBlock), 0, ctx->stream, in_a, in_b,
+                       in2_a, in2_b, c_b, kN, (const int32_t*)ctx->ksblob, ks_var, ctx->row_stride, ctx->P.n,
+                       ctx->P.n_ks, (int)B, out_a, out_b, var_out);
+  } else if (B >= (size_t)ctx->num_cus * kKsTile) {
     // enough ciphertexts to give every compute unit a tile: share the key reads
     const unsigned grid = (unsigned)((B + kKsTile - 1) / kKsTile);
     if (ctx->P.ks_t == 8)
