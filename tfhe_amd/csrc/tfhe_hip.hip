@@ -2337,8 +2337,13 @@ int launch_keyswitch(tfhe_hip_ctx* ctx, const int32_t* in_a, const int32_t* in_b
                      double* var_out, size_t B) {
   const double* ks_var = (const double*)(ctx->ksblob + ctx->ks_rows_bytes);
   ProfileScope prof(ctx, 2);
-  if (ctx->P.ks_t == 8 && B >= (size_t)ctx->num_cus * 2 * kKsLdsTile) {
-    // two tiles of the large form per compute unit and more: a quarter of the key reads
+  // The 32-ciphertext form runs one workgroup per compute unit, i.e. in rounds of 32 ciphertexts per
+  // compute unit, at about three quarters of the tile kernel's time per ciphertext when a round is
+  // full (measured: 8 192 gates 0.96 against 1.20 ms, 16 384 gates 1.96 against 2.81 ms on Bit80); it
+  // is used when its whole rounds cost less than the tile kernel's exact count.
+  const size_t lds_round = (size_t)ctx->num_cus * kKsLdsTile;
+  const size_t lds_rounds = (B + lds_round - 1) / lds_round;
+  if (ctx->P.ks_t == 8 && B >= lds_round && 3 * lds_rounds * lds_round < 4 * B) {
     const unsigned grid = (unsigned)((B + kKsLdsTile - 1) / kKsLdsTile);
     hipLaunchKernelGGL(keyswitch_lds_kernel<kKsLdsTile>, dim3(grid), dim3(kKsBlock), 0, ctx->stream, in_a, in_b,
                        in2_a, in2_b, c_b, kN, (const int32_t*)ctx->ksblob, ks_var, ctx->row_stride, ctx->P.n,
