@@ -495,7 +495,7 @@ def time_nand(eng, torch, dist, dev, world, rank, level, K, B, steps, warmup, ch
         "per_rank_value": per_rank,
         "roofline": {"bound": "fp64_valu",
                      # the throughput form the library's AUTO mode picks for this parameter set
-                     "kernel": {"batch": "blind_rotate_kernel", "split": "blind_rotate_split_kernel"}.get(
+                     "kernel": {"batch": "blind_rotate_kernel", "split": "blind_rotate_split64_kernel"}.get(
                          BLIND_ROTATE_MODE, "blind_rotate64_kernel"),
                      "achieved": achieved, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,

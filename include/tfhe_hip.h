@@ -123,15 +123,16 @@ int tfhe_hip_synchronize(tfhe_hip_ctx* ctx);
  * BATCH64: one ciphertext per wavefront, two wavefronts per SIMD; a transform takes
  *          the whole wavefront, the two digit polynomials run one after the other.
  *          Both are throughput forms with persistent workgroups.
- * SPLIT:   one ciphertext per workgroup, one wavefront per (decomposition level,
- *          result polynomial) pair of tgsw_extern_mul_to_tlwe (src/tgsw.rs:229-264);
- *          a third of the latency, 4/3 of the arithmetic.
- * AUTO (default): SPLIT while the batch has at most two ciphertexts per compute
- *          unit, BATCH up to one per SIMD, above that BATCH64 (the fastest throughput
- *          form on MI355X for both parameter sets), which takes the batch in whole
- *          rounds of one ciphertext per wavefront slot; a last round that would be at
- *          most half full runs as SPLIT or BATCH instead, after the full rounds on the
- *          same stream.
+ * SPLIT:   one ciphertext per workgroup, one wavefront per (digit polynomial, key
+ *          polynomial) product of tgsw_extern_mul_to_tlwe (src/tgsw.rs:229-264): 4 l
+ *          wavefronts; under a third of the latency, twice the forward transforms.
+ * AUTO (default): whole rounds of BATCH64 (one ciphertext per wavefront slot, the
+ *          fastest throughput form on MI355X for both parameter sets) and, for what is
+ *          left over, the cheapest of one more BATCH64 round, one BATCH round, SPLIT
+ *          rounds, or one BATCH round followed by SPLIT rounds, by measured cost per
+ *          round; the parts run one after another on the context's stream.  On 256
+ *          compute units: up to 768 gates SPLIT, up to 1024 BATCH, up to 1536 BATCH
+ *          then SPLIT, up to 2048 BATCH64.
  * Results are identical in every mode. */
 enum { TFHE_HIP_BR_AUTO = 0, TFHE_HIP_BR_BATCH = 1, TFHE_HIP_BR_SPLIT = 2, TFHE_HIP_BR_BATCH64 = 3 };
 int tfhe_hip_set_blind_rotate_mode(tfhe_hip_ctx* ctx, int mode);

@@ -332,15 +332,16 @@ def test_bootstrap_full_size_synthetic_keys(eng, level, B):
         assert (oa[i] == wa).all() and ob[i] == wb and var[i] == wv, i
 
 
-@pytest.mark.parametrize("level,B", [(80, 700), (80, 2049), (80, 2648), (128, 1030), (128, 2700)])
+@pytest.mark.parametrize("level,B", [(80, 700), (80, 900), (80, 2049), (80, 2648), (80, 3300), (128, 1030), (128, 2700)])
 def test_blind_rotate_mappings_agree_at_full_size(level, B):
     """Size-independent property at the bench's parameters: the two throughput mappings and
     the low-latency mapping return the same bits on a batch that spans several
     rounds of persistent workgroups (and the automatic choice equals all of them).  The sizes
-    walk the automatic mode's cases on a GPU of 256 compute units: 700 gates run with one
-    wavefront per SIMD, 1 030 in one (half empty) round of two wavefronts per SIMD, and after a
-    full round of 2 048 a remainder of 1 goes to the low-latency mapping, one of 600 or 652 to
-    the one-wavefront-per-SIMD mapping."""
+    walk the automatic mode's plans on a GPU of 256 compute units: 700 gates run in three rounds
+    of the low-latency mapping, 900 with one wavefront per SIMD, 1 030 as 1 024 of those and
+    6 in the low-latency mapping; after a full round of 2 048 with two wavefronts per SIMD a
+    remainder of 1, 600 or 652 goes to the low-latency mapping and one of 1 252 is divided
+    between the one-wavefront-per-SIMD mapping (1 024) and the low-latency one (228)."""
     import tfhe_amd
     P = orc.params(level)
     K = orc.generate_synthetic_keys(P, 90 + level)

@@ -72,10 +72,7 @@ struct StampCtx {
 
 
 // Low-latency kernel: the first loads of a wavefront's key block are issued before the
-// forward transform (1) or after it (0); depth of their software pipeline in groups of four.
-#ifndef TFHE_SPLIT_EARLY_KEY
-#define TFHE_SPLIT_EARLY_KEY 1
-#endif
+// forward transform; depth of their software pipeline in groups of four.
 #ifndef TFHE_SPLIT_KEY_DEPTH
 #define TFHE_SPLIT_KEY_DEPTH 3
 #endif
@@ -128,21 +125,16 @@ __device__ __forceinline__ MonomialPower monomial_power(int power) {
   return {power % kN, ((power / kN) & 1) != 0};
 }
 
-// Which form of the twist (wave_fft.hpp, SCALAR parameter of the twisted transforms) a kernel
-// uses: scalar loads in the kernels that keep one wavefront per SIMD busy on its own
-// ciphertext, the LDS table in the one-workgroup-per-ciphertext kernel (measured on MI355X:
-// +3..7 % throughput for the former, 4 % lower single-gate latency for the latter).
+// Which form of the twist (wave_fft.hpp, SCALAR parameter of the twisted transforms) the
+// half-wave kernels use: scalar loads (measured on MI355X: +3..7 % throughput over the LDS table
+// where one wavefront per SIMD is busy on its own ciphertext).
 #ifndef TFHE_BATCH_SCALAR_TWIST
 #define TFHE_BATCH_SCALAR_TWIST 1
-#endif
-#ifndef TFHE_SPLIT_SCALAR_TWIST
-#define TFHE_SPLIT_SCALAR_TWIST 0
 #endif
 #ifndef TFHE_POLYMUL_SCALAR_TWIST
 #define TFHE_POLYMUL_SCALAR_TWIST 1
 #endif
 constexpr bool kBatchScalar = TFHE_BATCH_SCALAR_TWIST != 0;
-constexpr bool kSplitScalar = TFHE_SPLIT_SCALAR_TWIST != 0;
 constexpr bool kPolymulScalar = TFHE_POLYMUL_SCALAR_TWIST != 0;
 
 // Copies the pair of twiddle tables a kernel's form of the twist needs (make_tables: 1024
@@ -334,22 +326,6 @@ struct RegisterSink {
     });
   }
 };
-// LdsSink: the same adds into an accumulator [2][N] shared by a workgroup in LDS.
-struct LdsSink {
-  unsigned* accL;
-  int h, q;
-  __device__ __forceinline__ int32_t prepare(double v) { return wfft::round_sat_i32(v); }
-  template <class RC>
-  __device__ __forceinline__ void own(RC, double v) {
-    atomicAdd(accL + h * kN + q + 32 * RC::value, (unsigned)prepare(v));
-  }
-  __device__ __forceinline__ void cross(int32_t (&x)[32]) {     // result polynomial 1 - h
-    static_for<0, 32>([&](auto ic) WFFT_INLINE {
-      constexpr int r = decltype(ic)::value;
-      atomicAdd(accL + (1 - h) * kN + q + 32 * r, (unsigned)x[r]);
-    });
-  }
-};
 
 template <int L, int BGBIT, class M = NoMargin>
 __device__ __forceinline__ void extprod_accumulate(unsigned (&acc_a)[32], const cplx* __restrict__ bk,
@@ -529,163 +505,6 @@ __global__ __launch_bounds__(kBlock, 1) void blind_rotate_kernel(BlindRotateArgs
       args.out_b[b] = barb >= 0 ? args.mu : wneg(args.mu);
     }
   }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Small batches: one WORKGROUP per ciphertext.  The (digit polynomial, key
-// polynomial) products of an external product are independent until their rounded
-// results meet in the accumulator.  With CPW = 1 wavefront w = 2 p + u takes level
-// p and result polynomial u: its half-wave h decomposes accumulator polynomial h,
-// transforms the digits, multiplies by K_{h,u} and transforms back; an iteration
-// then costs one forward and one inverse transform per wavefront instead of l and
-// 2 l, at the price of computing each forward transform twice.  With CPW = 2
-// wavefront w takes level w with both result polynomials (level_product).  Either
-// way the rounded products are added (wrapping, in LDS) into the shared
-// accumulator.  This is the low-latency form, used when the batch cannot fill the
-// machine with one ciphertext per wavefront; l = 3 uses CPW = 2 because six
-// wavefronts would have to share four SIMDs and half the registers.
-//
-// LDS: per wavefront the FFT exchange area, then per workgroup prev [2][N],
-// acc [2][N], tt [N][2] (int32), then the twiddle tables.
-// ---------------------------------------------------------------------------
-template <int W>
-constexpr int split_lds_bytes() {
-  return W * wfft::kExchangeBytes + 3 * 2 * kN * 4 + kTableBytes;
-}
-
-template <int L, int BGBIT, bool HOOK, int CPW>
-__global__ __launch_bounds__(64 * L * 2 / CPW, 1) void blind_rotate_split_kernel(BlindRotateArgs args) {
-  constexpr int W = L * 2 / CPW;
-  static_assert(W <= 4, "one wavefront per SIMD");
-  __shared__ __attribute__((aligned(16))) char lds[split_lds_bytes<W>()];
-  char* shared = lds + W * wfft::kExchangeBytes;
-  int32_t* prevL = reinterpret_cast<int32_t*>(shared);
-  int32_t* accL = prevL + 2 * kN;
-  int32_t* ttL = accL + 2 * kN;
-  char* lds_tables = shared + 3 * 2 * kN * 4;
-  load_tables<kSplitScalar>(lds_tables, args.tables);
-  const cplx* tE = reinterpret_cast<const cplx*>(lds_tables);
-  const cplx* tq = tE + 1024;
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int h = lane >> 5, q = lane & 31;
-  // CPW == 1: this wavefront's level p and result polynomial u
-  const int p = CPW == 1 ? wave >> 1 : wave, u = wave & 1;
-  char* wave_tiles = lds + wave * wfft::kExchangeBytes;
-  const int b = blockIdx.x;
-  constexpr uint32_t kMaskTt = tt_mask<L, BGBIT>();
-  const int decal = 32 - (p + 1) * BGBIT;
-  StampCtx st;
-  // wrapping add of a rounded, saturated product (numerics.rs:138-155)
-  LdsSink accumulate{reinterpret_cast<unsigned*>(accL), h, q};      // CPW == 2: level_product
-
-  for (int x = threadIdx.x; x < 2 * kN; x += 64 * W) {
-    prevL[x] = 0;                                              // bootstrapping.rs:116-117
-    accL[x] = HOOK ? args.acc_io[(size_t)b * 3 * kN + x] : 0;
-  }
-
-  const int32_t* bara = args.bara + (size_t)b * args.n;
-  int abar64 = 0;
-#pragma unroll 1
-  for (int i = 0; i < args.n; i++) {
-    if ((i & 63) == 0) abar64 = (i + lane < args.n) ? bara[i + lane] : 0;
-    const int abar = __builtin_amdgcn_readlane(abar64, i & 63);
-    if (abar == 0) continue;                                   // bootstrapping.rs:122-126
-    if (i == 0) st.start();
-    __syncthreads();                                           // acc of the last iteration is complete
-    TFHE_STAMP(st, 0);
-    // t = X^abar (prev + acc) - acc, rows r = wave, wave + W, ... of each polynomial
-    // (src/bootstrapping.rs:136-146, src/polynomial.rs:281-313); then prev <- acc.
-    {
-      const MonomialPower mp = monomial_power(abar);         // polynomial.rs:289-291
-      const int base = q - mp.pw;
-      constexpr int kRows = (32 + W - 1) / W;
-      int32_t keep[kRows];
-      static_for<0, kRows>([&](auto ic) WFFT_INLINE {
-        constexpr int e = decltype(ic)::value;
-        const int r = wave + W * e;
-        if (r < 32) {
-          const int n = q + 32 * r;
-          const int src = (base + 32 * r) & (kN - 1);
-          const int32_t v = wadd(prevL[h * kN + src], accL[h * kN + src]);
-          const int32_t a = accL[h * kN + n];
-          const int32_t x = ((base < -32 * r) != mp.cycle) ? wneg(v) : v;
-          ttL[2 * n + h] = (int32_t)((uint32_t)wsub(x, a) ^ kMaskTt);
-          keep[e] = a;
-        }
-      });
-      TFHE_STAMP(st, 1);
-      __syncthreads();                                         // tt complete, prev no longer read
-      TFHE_STAMP(st, 2);
-      static_for<0, kRows>([&](auto ic) WFFT_INLINE {
-        constexpr int e = decltype(ic)::value;
-        const int r = wave + W * e;
-        if (r < 32) prevL[h * kN + q + 32 * r] = keep[e];
-      });
-    }
-    const char* tt = reinterpret_cast<const char*>(ttL) + q * 8;
-    if constexpr (CPW == 2) {
-      level_product<BGBIT, kSplitScalar>(p, tt, args.bkfft + ((size_t)i * L + p) * 2 * 2048, wave_tiles, tE, tq,
-                                         lane, accumulate, st);
-    } else {
-    // this wavefront's level p and result polynomial u: half-wave h takes digit polynomial
-    // h, so both halves contribute (each rounded on its own) to the same result polynomial
-    char* tile = wave_tiles + h * wfft::kHalfBytes;
-    double re[32], im[32];
-    static_for<0, 32>([&](auto ic) WFFT_INLINE {
-      constexpr int r = decltype(ic)::value;
-      const int32_t t = *reinterpret_cast<const int32_t*>(tt + 4 * h + r * 256);
-      re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(t, decal, BGBIT);
-    });
-    TFHE_STAMP(st, 3);
-    // K_{h,u}: block 0 of the level holds K_{h,h}, block 1 K_{h,1-h}; the first loads are
-    // issued before the forward transform (a single ciphertext's key comes from HBM)
-    const cplx* kcol = args.bkfft + ((size_t)i * L + p) * 2 * 2048 + (h == u ? 0 : 2048) + lane;
-    auto load_k = [&](auto ic) WFFT_INLINE { return kcol[decltype(ic)::value * 64]; };
-    wfft::Pipe32<4, TFHE_SPLIT_KEY_DEPTH, cplx> kp;
-#if TFHE_SPLIT_EARLY_KEY
-    kp.prologue(load_k);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-    wfft::fwd1024_twisted_real<kSplitScalar>(re, im, tile, tE, tq, q);
-    TFHE_STAMP(st, 4);
-#if !TFHE_SPLIT_EARLY_KEY
-    kp.prologue(load_k);
-#endif
-    TFHE_STAMP(st, 5);
-    kp.run2(load_k, [&](auto i0, const cplx& ka, auto i1, const cplx& kb) WFFT_INLINE {
-      constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;
-      wfft::cmul2<false>(re[s0], im[s0], ka, re[s1], im[s1], kb);
-    });
-    TFHE_STAMP(st, 6);
-    wfft::inv1024_twisted_real<false, kSplitScalar>(
-        re, im, tile, tE, tq, q,
-        [&](auto rc, double v) WFFT_INLINE {
-          constexpr int r = decltype(rc)::value;
-          atomicAdd(reinterpret_cast<unsigned*>(accL) + u * kN + q + 32 * r, (unsigned)wfft::round_sat_i32(v));
-        },
-        [](auto, double) {});
-    TFHE_STAMP(st, 7);
-    }
-  }
-#ifdef TFHE_STAMPS
-  if (b == 0 && lane == 0 && (wave == 0 || wave == W - 1))
-    for (int k = 0; k < 8; k++) g_stamps[(wave ? 8 : 0) + k] = st.acc[k];
-#endif
-  __syncthreads();
-
-  if (HOOK) {
-    for (int x = threadIdx.x; x < 2 * kN; x += 64 * W) args.acc_io[(size_t)b * 3 * kN + x] = accL[x];
-  } else {
-    // extract_lwe, src/tlwe.rs:159-180 (k = 1): a[0] = acc0[0], a[t] = -acc0[N-t].
-    int32_t* oa = args.out_a + (size_t)b * kN;
-    for (int t = threadIdx.x; t < kN; t += 64 * W) oa[t] = t == 0 ? accL[0] : wneg(accL[kN - t]);
-    if (threadIdx.x == 0) {
-      const int32_t barb = args.barb[b];                       // bootstrapping.rs:58-96
-      args.out_b[b] = barb >= 0 ? args.mu : wneg(args.mu);
-    }
   }
 }
 
@@ -1202,6 +1021,123 @@ __global__ __launch_bounds__(64 * kWaves64) void blind_rotate64_kernel(BlindRota
         const int32_t barb = args.barb[b];                       // bootstrapping.rs:58-96
         args.out_b[b] = barb >= 0 ? args.mu : wneg(args.mu);
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Low-latency mapping on the transforms of wave_fft64.hpp: one workgroup per ciphertext, one
+// WAVEFRONT per (digit polynomial, key polynomial) product of tgsw_extern_mul_to_tlwe
+// (src/tgsw.rs:229-264): wavefront ((p 2 + h) 2 + u) decomposes accumulator polynomial h at level p,
+// transforms the digits, multiplies by K_{h,u} and, after the inverse transform, adds its rounded
+// product into the shared accumulator in LDS (ds_add_u32; each product rounded on its own).
+// 4 l wavefronts, i.e. l per SIMD, whose round trips overlap; an iteration costs the latency of one
+// forward and one inverse transform (each forward transform is computed twice).  The accumulator,
+// the previous accumulator and the sample being decomposed are shared in LDS ([2][N] int32 each,
+// the sample XORed with tt_mask); two workgroup barriers per iteration order the rotation.
+// ---------------------------------------------------------------------------
+template <int L>
+constexpr int split64_lds_bytes() {
+  return 4 * L * wfft64::kTileBytes + 3 * 2 * kN * 4 + wfft64::kTableBytes;
+}
+
+template <int L, int BGBIT, bool HOOK>
+__global__ __launch_bounds__(64 * 4 * L) void blind_rotate_split64_kernel(BlindRotateArgs args) {
+  constexpr int W = 4 * L;
+  __shared__ __attribute__((aligned(16))) char lds[split64_lds_bytes<L>()];
+  char* shared = lds + W * wfft64::kTileBytes;
+  int32_t* prevL = reinterpret_cast<int32_t*>(shared);
+  int32_t* accL = prevL + 2 * kN;
+  int32_t* ttL = accL + 2 * kN;
+  const wfft64::Tables tb = load_tables64(shared + 3 * 2 * kN * 4, args.tables64);
+  const int lane0 = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int p = wave >> 2, h = (wave >> 1) & 1, u = wave & 1;
+  char* tile = lds + wave * wfft64::kTileBytes;
+  const int b = blockIdx.x;
+  constexpr uint32_t kMaskTt = tt_mask<L, BGBIT>();
+  const int decal = 32 - (p + 1) * BGBIT;
+
+  for (int x = threadIdx.x; x < 2 * kN; x += 64 * W) {
+    prevL[x] = 0;                                              // bootstrapping.rs:116-117
+    accL[x] = HOOK ? args.acc_io[(size_t)b * 3 * kN + x] : 0;
+  }
+
+  const int32_t* bara = args.bara + (size_t)b * args.n;
+  int abar64 = 0;
+#pragma unroll 1
+  for (int i = 0; i < args.n; i++) {
+    if ((i & 63) == 0) abar64 = (i + lane0 < args.n) ? bara[i + lane0] : 0;
+    const int abar = __builtin_amdgcn_readlane(abar64, i & 63);
+    if (abar == 0) continue;                                   // bootstrapping.rs:122-126
+    __syncthreads();                                           // acc of the last iteration is complete
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));                             // keeps per-lane addresses out of the loop's live-in set
+    // t = X^abar (prev + acc) - acc (src/bootstrapping.rs:136-146, src/polynomial.rs:281-313), the
+    // 2 N coefficients spread over the workgroup's threads; then prev <- acc.
+    {
+      const MonomialPower mp = monomial_power(abar);         // polynomial.rs:289-291
+      constexpr int kSteps = (2 * kN + 64 * W - 1) / (64 * W);
+      int32_t keep[kSteps];
+      static_for<0, kSteps>([&](auto ec) WFFT_INLINE {
+        constexpr int e = decltype(ec)::value;
+        const int x = (int)threadIdx.x + 64 * W * e;           // index into [2][N]
+        if (x < 2 * kN) {
+          const int hh = x >> 10, n = x & (kN - 1);
+          const int src = (n - mp.pw) & (kN - 1);
+          const int32_t v = wadd(prevL[hh * kN + src], accL[hh * kN + src]);
+          const int32_t a = accL[x];
+          const int32_t y = ((n < mp.pw) != mp.cycle) ? wneg(v) : v;
+          ttL[x] = (int32_t)((uint32_t)wsub(y, a) ^ kMaskTt);
+          keep[e] = a;
+        }
+      });
+      __syncthreads();                                         // tt complete, prev no longer read
+      static_for<0, kSteps>([&](auto ec) WFFT_INLINE {
+        constexpr int e = decltype(ec)::value;
+        const int x = (int)threadIdx.x + 64 * W * e;
+        if (x < 2 * kN) prevL[x] = keep[e];
+      });
+    }
+    double re[16], im[16];
+    static_for<0, 16>([&](auto rc) WFFT_INLINE {
+      constexpr int r = decltype(rc)::value;
+      re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(ttL[h * kN + lane + 64 * r], decal, BGBIT);
+    });
+    // K_{h,u}: block 0 of the level holds K_{h,h}, block 1 K_{h,1-h}, in the lane layout that
+    // level_product64 explains; the first loads go out before the forward transform (a single
+    // ciphertext's key comes from HBM, not from L2)
+    const int key_lane = (((lane >> 3) & 1) * 16) * 64 + h * 32 + (((lane >> 4) << 2) | (lane & 3)) +
+                         16 * ((lane >> 2) & 1);
+    const cplx* kcol = args.bkfft + ((size_t)i * L + p) * 4 * 1024 + (h == u ? 0 : 2048) + key_lane;
+    auto load_k = [&](auto ic) WFFT_INLINE { return kcol[decltype(ic)::value * 64]; };
+    wfft64::Pipe16<4, TFHE_SPLIT_KEY_DEPTH, cplx> kp;
+    kp.prologue(load_k);
+    __builtin_amdgcn_sched_barrier(0);
+    wfft64::fwd1024_twisted_real(re, im, tile, tb, lane);
+    kp.run2(load_k, [&](auto i0, const cplx& k0, auto i1, const cplx& k1) WFFT_INLINE {
+      constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;
+      wfft::cmul2<false>(re[s0], im[s0], k0, re[s1], im[s1], k1);
+    });
+    wfft64::inv1024_twisted_real<false>(
+        re, im, tile, tb, lane,
+        [&](auto rc, double v) WFFT_INLINE {
+          constexpr int r = decltype(rc)::value;
+          atomicAdd(reinterpret_cast<unsigned*>(accL) + u * kN + lane + 64 * r, (unsigned)wfft::round_sat_i32(v));
+        },
+        [](auto, double) {});
+  }
+  __syncthreads();
+
+  if (HOOK) {
+    for (int x = threadIdx.x; x < 2 * kN; x += 64 * W) args.acc_io[(size_t)b * 3 * kN + x] = accL[x];
+  } else {
+    // extract_lwe, src/tlwe.rs:159-180 (k = 1): a[0] = acc0[0], a[t] = -acc0[N-t].
+    int32_t* oa = args.out_a + (size_t)b * kN;
+    for (int t = threadIdx.x; t < kN; t += 64 * W) oa[t] = t == 0 ? accL[0] : wneg(accL[kN - t]);
+    if (threadIdx.x == 0) {
+      const int32_t barb = args.barb[b];                       // bootstrapping.rs:58-96
+      args.out_b[b] = barb >= 0 ? args.mu : wneg(args.mu);
     }
   }
 }
@@ -2253,11 +2189,11 @@ int launch_blind_rotate_mode(tfhe_hip_ctx* ctx, int mode, hipStream_t stream, co
   if (mode == TFHE_HIP_BR_SPLIT) {
     const dim3 grid((unsigned)B);
     if (ctx->P.l == 2) {
-      if (hook) hipLaunchKernelGGL((blind_rotate_split_kernel<2, 10, true, 1>), grid, dim3(256), 0, stream, a);
-      else hipLaunchKernelGGL((blind_rotate_split_kernel<2, 10, false, 1>), grid, dim3(256), 0, stream, a);
+      if (hook) hipLaunchKernelGGL((blind_rotate_split64_kernel<2, 10, true>), grid, dim3(512), 0, stream, a);
+      else hipLaunchKernelGGL((blind_rotate_split64_kernel<2, 10, false>), grid, dim3(512), 0, stream, a);
     } else {
-      if (hook) hipLaunchKernelGGL((blind_rotate_split_kernel<3, 7, true, 2>), grid, dim3(192), 0, stream, a);
-      else hipLaunchKernelGGL((blind_rotate_split_kernel<3, 7, false, 2>), grid, dim3(192), 0, stream, a);
+      if (hook) hipLaunchKernelGGL((blind_rotate_split64_kernel<3, 7, true>), grid, dim3(768), 0, stream, a);
+      else hipLaunchKernelGGL((blind_rotate_split64_kernel<3, 7, false>), grid, dim3(768), 0, stream, a);
     }
   } else if (mode == TFHE_HIP_BR_BATCH64) {
     const unsigned grid = (unsigned)std::min<size_t>(B, (size_t)ctx->num_cus);
@@ -2304,32 +2240,44 @@ int launch_blind_rotate(tfhe_hip_ctx* ctx, const int32_t* bara, const int32_t* b
     return 0;
   }
 #endif
-  // Which mapping a batch gets in automatic mode (measured on MI355X, both parameter sets,
-  // tools/time_batch_sizes.py): up to two ciphertexts per compute unit one workgroup per ciphertext
-  // (2 l wavefronts each, a third of the latency); up to one per SIMD the persistent form with one
-  // wavefront per SIMD (a tenth faster than the two-wavefront form running half empty); above
-  // that the persistent form with two wavefronts per SIMD, which takes the batch in rounds of one
-  // ciphertext per wavefront slot.  A last round that would be at most half full costs a whole
-  // round there, so that remainder runs in one of the first two forms instead, after the full
-  // rounds on the same stream.
-  const size_t small = 2 * (size_t)ctx->num_cus;
-  const size_t slots32 = (size_t)ctx->num_cus * kWavesPerBlock, slots64 = (size_t)ctx->num_cus * kWaves64;
+  // Which mappings a batch gets in automatic mode.  Each mapping takes its ciphertexts in rounds:
+  // one workgroup per ciphertext (SPLIT) a compute unit's worth, the persistent form with one
+  // wavefront per SIMD (BATCH) four per compute unit, the one with two wavefronts per SIMD
+  // (BATCH64) eight, and a round costs the same whether full or not.  Measured on MI355X
+  // (tools/time_batch_sizes.py) the rounds cost 0.31 : 1 : 1.75 at both parameter sets, so whole
+  // BATCH64 rounds are the cheapest per ciphertext and what is left over after them goes to the
+  // cheapest of: one more BATCH64 round; one BATCH round; SPLIT rounds; one BATCH round and SPLIT
+  // rounds.  The parts run one after another on the context's stream.
   ProfileScope prof(ctx, 1);
   if (ctx->br_mode != TFHE_HIP_BR_AUTO) return launch_blind_rotate_mode(ctx, ctx->br_mode, ctx->stream, a, B);
-  if (B <= small) return launch_blind_rotate_mode(ctx, TFHE_HIP_BR_SPLIT, ctx->stream, a, B);
-  if (B <= slots32) return launch_blind_rotate_mode(ctx, TFHE_HIP_BR_BATCH, ctx->stream, a, B);
-  const size_t rem = B % slots64, full = B - rem;
-  if (rem == 0 || rem > slots32) return launch_blind_rotate_mode(ctx, TFHE_HIP_BR_BATCH64, ctx->stream, a, B);
-  BlindRotateArgs tail = a;
-  tail.bara = bara + full * (size_t)ctx->P.n;
-  if (barb) tail.barb = barb + full;
-  if (acc_io) tail.acc_io = acc_io + full * 3 * kN;
-  if (out_a) tail.out_a = out_a + full * kN;
-  if (out_b) tail.out_b = out_b + full;
-  tail.B = (int32_t)rem;
-  a.B = (int32_t)full;
-  if (int rc = launch_blind_rotate_mode(ctx, TFHE_HIP_BR_BATCH64, ctx->stream, a, full)) return rc;
-  return launch_blind_rotate_mode(ctx, rem <= small ? TFHE_HIP_BR_SPLIT : TFHE_HIP_BR_BATCH, ctx->stream, tail, rem);
+  constexpr size_t kCostSplit = 31, kCostBatch = 100, kCostBatch64 = 175;
+  const size_t cus = (size_t)ctx->num_cus;
+  const size_t slots32 = cus * kWavesPerBlock, slots64 = cus * kWaves64;
+  const size_t rem = B % slots64;
+  size_t n64 = B - rem, n32 = 0, nsplit = 0;               // ciphertexts per mapping, in this order
+  if (rem) {
+    const size_t over = rem > slots32 ? rem - slots32 : 0;  // what one BATCH round leaves
+    const size_t cost_split = (rem + cus - 1) / cus * kCostSplit;
+    const size_t cost_batch = kCostBatch + (over + cus - 1) / cus * kCostSplit;
+    if (kCostBatch64 <= cost_split && kCostBatch64 <= cost_batch) n64 = B;
+    else if (cost_split <= cost_batch) nsplit = rem;
+    else { n32 = rem - over; nsplit = over; }
+  }
+  size_t done = 0;
+  const size_t parts[3][2] = {{n64, TFHE_HIP_BR_BATCH64}, {n32, TFHE_HIP_BR_BATCH}, {nsplit, TFHE_HIP_BR_SPLIT}};
+  for (const auto& part : parts) {
+    if (part[0] == 0) continue;
+    BlindRotateArgs sub = a;
+    sub.bara = bara + done * (size_t)ctx->P.n;
+    if (barb) sub.barb = barb + done;
+    if (acc_io) sub.acc_io = acc_io + done * 3 * kN;
+    if (out_a) sub.out_a = out_a + done * kN;
+    if (out_b) sub.out_b = out_b + done;
+    sub.B = (int32_t)part[0];
+    if (int rc = launch_blind_rotate_mode(ctx, (int)part[1], ctx->stream, sub, part[0])) return rc;
+    done += part[0];
+  }
+  return 0;
 }
 
 int launch_keyswitch(tfhe_hip_ctx* ctx, const int32_t* in_a, const int32_t* in_b, const int32_t* in2_a,

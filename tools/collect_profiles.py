@@ -19,7 +19,7 @@ R = sys.argv[1]
 
 
 def kernel_key(name):
-    for k in ("blind_rotate_split_kernel", "blind_rotate64_kernel", "blind_rotate_kernel", "keyswitch_tile_kernel", "keyswitch_kernel",
+    for k in ("blind_rotate_split64_kernel", "blind_rotate64_kernel", "blind_rotate_kernel", "keyswitch_tile_kernel", "keyswitch_kernel",
               "prologue_kernel", "polymul64_kernel", "polymul2_kernel", "polymul_kernel", "bk_fft_kernel"):
         if k in name:
             return k
