@@ -60,7 +60,9 @@ for sub, o in (("prof", "bench_kernel_stats"), ("prof_polymul", "polymul_kernel_
             print(row["Name"][:60], row["Calls"], row["AverageNs"], row["Percentage"])
     shutil.copy(ks, f"{P}/{PRE}_{o}.csv")
 shutil.copy(R + "/bench_prof.log", f"{P}/{PRE}_bench_under_rocprof.log")
-for name in ("valu_cost_ubench.txt", "lds_cost_ubench.txt"):
+if os.path.exists(R + "/strong_1M_gates.json"):
+    shutil.copy(R + "/strong_1M_gates.json", f"{P}/{PRE}_bench_strong_1M_gates.json")
+for name in ("valu_cost_ubench.txt", "lds_cost_ubench.txt", "batch_sizes.txt"):
     if os.path.exists(R + "/" + name):
         shutil.copy(R + "/" + name, f"{P}/{PRE}_{name}")
 sums = json.load(open(R + "/pmc_sums.json"))

@@ -14,6 +14,11 @@ $T 200 python bench.py --level 128 --steps 5 --no-polymul --no-add32 --no-textbo
 $T 200 python bench.py --keys reference --steps 5 $Q > $P/bench80_refkeys.json 2>> $P/bench80.err || exit 1
 $T 300 python bench.py --workload add32 --steps 1 --warmup 0 > $P/add32.json 2>> $P/bench80.err || exit 1
 $T 200 python bench.py --workload polymul > $P/polymul.json 2>> $P/bench80.err || exit 1
+# BASELINE config 4 on one GPU: 2^20 gates per step in launches of 16 384
+$T 300 python bench.py --total-gates 1048576 --steps 1 --warmup 0 $Q > $P/strong_1M_gates.json 2>> $P/bench80.err || exit 1
+# whole-gate time by batch size and mapping (thresholds of the automatic mode)
+$T 300 python tools/time_batch_sizes.py 1 64 256 257 512 513 768 769 1024 1025 1280 1536 1537 2048 2049 2304 2816 3072 3300 4096 5000 > $P/batch_sizes.txt 2>> $P/bench80.err || exit 1
+$T 300 python tools/time_batch_sizes.py --level 128 1 256 512 768 769 1024 1025 1536 1537 2048 2304 3072 3300 4096 >> $P/batch_sizes.txt 2>> $P/bench80.err || exit 1
 $T 300 rocprofv3 --kernel-trace --stats -d $P/prof -o vm --output-format csv -- python3 bench.py --steps 3 $Q > $P/bench_prof.log 2>&1 || exit 1
 $T 300 rocprofv3 --kernel-trace --stats -d $P/prof_polymul -o vm --output-format csv -- python3 bench.py --workload polymul > $P/polymul_prof.log 2>&1 || exit 1
 ONE="python3 bench.py --steps 1 --warmup 0 $Q"
