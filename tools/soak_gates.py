@@ -20,7 +20,7 @@ while time.time() - t0 < float(sys.argv[2]) if len(sys.argv) > 2 else 120:
     K = orc.generate_synthetic_keys(P, seed)
     eng.load_keys(tfhe_amd.make_params(P.n, l=l, bg_bit=bg, n_ks=P.n_ks), K["bk"], K["ks_a"], K["ks_b"], K["ks_var"])
     mode = ("auto", "batch", "batch64", "split")[int(rng.integers(0, 4))]
-    if mode == "split" and B > 600: mode = "batch64"
+    if mode == "split" and B > 1100: mode = "batch64"
     eng.set_blind_rotate_mode(mode)
     mk = lambda s, shape: orc.uniform_i32(seed + s, shape)
     ca, cb, cc = (mk(1, (B, n)), mk(2, (B,))), (mk(3, (B, n)), mk(4, (B,))), (mk(5, (B, n)), mk(6, (B,)))
