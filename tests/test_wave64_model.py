@@ -33,3 +33,13 @@ def test_twisted_product_is_the_linear_convolution():
     c = np.convolve(a.astype(object), b.astype(object))
     c = np.array(list(c) + [0], dtype=np.float64)
     assert np.abs(lo - c[:1024]).max() < 0.25 and np.abs(hi - c[1024:]).max() < 0.25
+
+
+def test_twiddle_after_the_exchange_equals_twiddle_before_it():
+    """The kernel applies T1 after the lane/register exchange, inside the first half of the
+    4-point pass, reading the table at the permuted index: same transform."""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(1024) + 1j * rng.standard_normal(1024)
+    v = m.to_regs(x)
+    assert np.abs(m.forward_t1_fused(v) - m.forward(v)).max() < 1e-10
+    assert np.abs(m.forward_t1_fused(v, m.T1_TWISTED) - m.forward(v, m.T1_TWISTED)).max() < 1e-10

@@ -93,6 +93,28 @@ def forward(v, table=T1):
     return dft16(row_transpose(v), False)
 
 
+def t1_after_exchange(table=T1):
+    """T1 as the kernel reads it when the twiddle is applied AFTER step 3: the element now in lane
+    (a | ql), register y came from lane (y3 y2 | ql), register (a1 a0 y1 y0) = kr."""
+    y = _reg[:, None]
+    lane = _lane[None, :]
+    kr = ((lane >> 4) << 2) | (y & 3)
+    src_lane = ((y >> 2) << 4) | (lane & 15)
+    return table[kr, src_lane]
+
+
+def forward_t1_fused(v, table=T1):
+    """forward() with T1 inside the first half of the 4-point pass, as the kernel computes it:
+    a' = wa a + wb b, b' = wa a - wb b on the register pairs (y, y | 8), then the second half."""
+    v = lanes_to_regs(dft16(v, False)) * t1_after_exchange(table)
+    s, d = v[:8] + v[8:], v[:8] - v[8:]          # rows 0..3: (x0 +- x2)[j], rows 4..7: (x1 +- x3)[j]
+    out = np.empty_like(v)
+    out[0:4], out[8:12] = s[:4] + s[4:], s[:4] - s[4:]
+    out[4:8], out[12:16] = d[:4] - 1j * d[4:], d[:4] + 1j * d[4:]
+    out = out * np.repeat(T2, 4, axis=0)
+    return dft16(row_transpose(out), False)
+
+
 def inverse(V, table=T1):
     v = row_transpose(dft16(V, True))
     v = v * np.repeat(T2, 4, axis=0).conj()

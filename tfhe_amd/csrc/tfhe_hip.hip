@@ -71,6 +71,13 @@ struct StampCtx {
 #endif
 
 
+// Kernels on the wavefront-per-transform transforms: the pointwise product of two spectra inside
+// the first radix-2 stage of the inverse transform that follows it (wfft64::butterfly_ww: ten
+// instructions per pair of spectrum values instead of twelve).
+#ifndef TFHE_PRODUCT_STAGE1
+#define TFHE_PRODUCT_STAGE1 1
+#endif
+
 // Low-latency kernel: the first loads of a wavefront's key block are issued before the
 // forward transform; depth of their software pipeline in groups of four.
 #ifndef TFHE_SPLIT_KEY_DEPTH
@@ -678,6 +685,12 @@ __global__ __launch_bounds__(64 * kWaves64) void polymul64_kernel(const int32_t*
       wfft64::fwd1024_twisted_real<4>(re, im, tile, tb, lane);
     }
     __builtin_amdgcn_sched_barrier(0);
+#if TFHE_PRODUCT_STAGE1
+    static_for<0, 8>([&](auto mc) WFFT_INLINE {
+      constexpr int p0 = 2 * decltype(mc)::value, p1 = p0 + 1;
+      wfft64::butterfly_ww<false>(re[p0], im[p0], re[p1], im[p1], cplx{pre[p0], pim[p0]}, cplx{pre[p1], pim[p1]});
+    });
+#else
     wfft::chunked_for32<4>([&](auto ic) WFFT_INLINE {
       constexpr int p = decltype(ic)::value;
       if constexpr (p < 16) {
@@ -687,10 +700,11 @@ __global__ __launch_bounds__(64 * kWaves64) void polymul64_kernel(const int32_t*
         im[p] = pr * qi + pi * qr;
       }
     });
+#endif
     __builtin_amdgcn_sched_barrier(0);
     const int lane = fresh_lane();
     // afterwards re = coefficients t < N, im = coefficients N + t of this product, t = lane + 64 r
-    wfft64::inv1024_twisted_real<!ACCUMULATE, 4>(
+    wfft64::inv1024_twisted_real<!ACCUMULATE, 4, TFHE_PRODUCT_STAGE1 != 0>(
         re, im, tile, tb, lane,
         [&](auto rc, double v) WFFT_INLINE { re[decltype(rc)::value] = v; },
         [&](auto rc, double v) WFFT_INLINE { im[decltype(rc)::value] = v; });
@@ -867,14 +881,18 @@ __device__ __forceinline__ void level_product64(int p, const TT& tt, const cplx*
       kp.prologue(load_a);
       kp.run2(load_a, [&](auto i0, const cplx& k0, auto i1, const cplx& k1) WFFT_INLINE {
         constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;
+#if TFHE_PRODUCT_STAGE1
+        wfft64::butterfly_ww_to(re[s0], im[s0], re[s1], im[s1], k0, k1, zr[s0], zi[s0], zr[s1], zi[s1]);
+#else
         zr[s0] = re[s0] * k0.x - im[s0] * k0.y;
         zi[s0] = re[s0] * k0.y + im[s0] * k0.x;
         zr[s1] = re[s1] * k1.x - im[s1] * k1.y;
         zi[s1] = re[s1] * k1.y + im[s1] * k1.x;
+#endif
       });
     }
     RegisterSink64 sink{acc};
-    wfft64::inv1024_twisted_real<false>(
+    wfft64::inv1024_twisted_real<false, WFFT64_TW_GROUP, TFHE_PRODUCT_STAGE1 != 0>(
         zr, zi, tile, tb, lane, [&](auto rc, double v) WFFT_INLINE { sink.template add<h>(rc, v, margin); },
         [](auto, double) {});
     {
@@ -882,10 +900,14 @@ __device__ __forceinline__ void level_product64(int p, const TT& tt, const cplx*
       kp.prologue(load_b);
       kp.run2(load_b, [&](auto i0, const cplx& k0, auto i1, const cplx& k1) WFFT_INLINE {
         constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;
+#if TFHE_PRODUCT_STAGE1
+        wfft64::butterfly_ww<false>(re[s0], im[s0], re[s1], im[s1], k0, k1);
+#else
         wfft::cmul2<false>(re[s0], im[s0], k0, re[s1], im[s1], k1);
+#endif
       });
     }
-    wfft64::inv1024_twisted_real<false>(
+    wfft64::inv1024_twisted_real<false, WFFT64_TW_GROUP, TFHE_PRODUCT_STAGE1 != 0>(
         re, im, tile, tb, lane, [&](auto rc, double v) WFFT_INLINE { sink.template add<1 - h>(rc, v, margin); },
         [](auto, double) {});
   });
@@ -1117,9 +1139,13 @@ __global__ __launch_bounds__(64 * 4 * L) void blind_rotate_split64_kernel(BlindR
     wfft64::fwd1024_twisted_real(re, im, tile, tb, lane);
     kp.run2(load_k, [&](auto i0, const cplx& k0, auto i1, const cplx& k1) WFFT_INLINE {
       constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;
+#if TFHE_PRODUCT_STAGE1
+      wfft64::butterfly_ww<false>(re[s0], im[s0], re[s1], im[s1], k0, k1);
+#else
       wfft::cmul2<false>(re[s0], im[s0], k0, re[s1], im[s1], k1);
+#endif
     });
-    wfft64::inv1024_twisted_real<false>(
+    wfft64::inv1024_twisted_real<false, WFFT64_TW_GROUP, TFHE_PRODUCT_STAGE1 != 0>(
         re, im, tile, tb, lane,
         [&](auto rc, double v) WFFT_INLINE {
           constexpr int r = decltype(rc)::value;
@@ -2382,6 +2408,19 @@ void make_w64(double (&w)[32]) {
   }
 }
 
+// wfft64::g_inv64: for b = 0..7 the factors alpha = w64^-b, beta = w16^-b alpha, alpha' = w64^-(b+8),
+// beta' = w16^-b alpha' (w_n = exp(-2 pi i / n)), as (re, im) pairs
+void make_inv64(double (&w)[64]) {
+  const long double two_pi = 6.283185307179586476925286766559L;
+  for (int b = 0; b < 8; b++) {
+    const int sixtyfourths[4] = {b, 5 * b, b + 8, 5 * b + 8};
+    for (int k = 0; k < 4; k++) {
+      w[8 * b + 2 * k] = (double)cosl(two_pi * (long double)sixtyfourths[k] / 64.0L);
+      w[8 * b + 2 * k + 1] = (double)sinl(two_pi * (long double)sixtyfourths[k] / 64.0L);
+    }
+  }
+}
+
 // (cos, -sin)(2 pi r / 128) for wfft::g_w128
 void make_w128(double (&w)[64]) {
   const long double two_pi = 6.283185307179586476925286766559L;
@@ -2497,9 +2536,11 @@ int tfhe_hip_create(tfhe_hip_ctx** out, int device) {
   }
   std::vector<cplx> t64;
   make_tables64(t64);
-  double w64[32];
+  double w64[32], inv64[64];
   make_w64(w64);
+  make_inv64(inv64);
   if (hipMemcpyToSymbol(HIP_SYMBOL(wfft64::g_w64), w64, sizeof(w64)) != hipSuccess ||
+      hipMemcpyToSymbol(HIP_SYMBOL(wfft64::g_inv64), inv64, sizeof(inv64)) != hipSuccess ||
       hipMalloc((void**)&ctx->tables64, t64.size() * sizeof(cplx)) != hipSuccess ||
       hipMemcpy(ctx->tables64, t64.data(), t64.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) {
     tfhe_hip_destroy(ctx);

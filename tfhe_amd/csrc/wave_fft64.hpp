@@ -51,6 +51,17 @@ __device__ __forceinline__ wfft::const_seg_ptr w64_ptr() {
   return p;
 }
 
+// For butterfly b = 0..7 of the inverse transform's last radix-2 stage (a = y[b], c = y[b + 8],
+// W = w16^-b) with the register part of the untwist folded in: alpha = w64^-b, beta = W alpha,
+// alpha' = w64^-(b + 8), beta' = W alpha', as (re, im) pairs in this order.
+__constant__ double g_inv64[64];
+
+__device__ __forceinline__ wfft::const_seg_ptr inv64_ptr() {
+  wfft::const_seg_ptr p = (wfft::const_seg_ptr)g_inv64;
+  asm volatile("" : "+s"(p));
+  return p;
+}
+
 __host__ __device__ constexpr int br4(int v) {
   return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3);
 }
@@ -120,6 +131,48 @@ __device__ __forceinline__ void inv16(double (&re)[16], double (&im)[16]) {
   dit_stage<2, true, false>(re, im);
   dit_stage<4, true, false>(re, im);
   dit_stage<8, true, false>(re, im);
+}
+
+// The register part w64^r of the twist inside the first stage of the forward 16-point pass
+// (whose butterflies pair registers r and r + 8, without twiddles): for REAL inputs x = re[r],
+// y = re[r + 8] the outputs x w64^r +- y w64^(r+8) cost six instructions per butterfly instead of
+// four products and four additions.
+#ifndef WFFT64_FUSED_TWIST
+#define WFFT64_FUSED_TWIST 1
+#endif
+__device__ __forceinline__ void fwd16_first_stage_twisted_real(double (&re)[16], double (&im)[16]) {
+  static_for<0, 4>([&](auto gc) WFFT_INLINE {
+    wfft::const_seg_ptr g = w64_ptr();
+    static_for<0, 2>([&](auto ic) WFFT_INLINE {
+      constexpr int r = decltype(gc)::value * 2 + decltype(ic)::value;
+      const double c0 = g[2 * r], s0 = g[2 * r + 1], c1 = g[2 * r + 16], s1 = g[2 * r + 17];
+      const double x = re[r], y = re[r + 8];
+      const double pr = x * c0, pi = x * s0;
+      re[r] = __builtin_fma(y, c1, pr);
+      im[r] = __builtin_fma(y, s1, pi);
+      re[r + 8] = __builtin_fma(-y, c1, pr);
+      im[r + 8] = __builtin_fma(-y, s1, pi);
+    });
+  });
+}
+// The last stage of the inverse 16-point pass with the register part of the untwist, when only
+// the real part of y conj(w64^r) is wanted: Re((a +- W c) alpha) in four instructions per output
+// instead of a butterfly (six, or four without a twiddle) and two per output.
+template <class Lo>
+__device__ __forceinline__ void inv16_last_stage_untwisted_real(double (&re)[16], double (&im)[16], Lo&& lo) {
+  static_for<0, 4>([&](auto gc) WFFT_INLINE {
+    wfft::const_seg_ptr g = inv64_ptr();
+    static_for<0, 2>([&](auto ic) WFFT_INLINE {
+      constexpr int b = decltype(gc)::value * 2 + decltype(ic)::value;
+      const double ar = re[b], ai = im[b], cr = re[b + 8], ci = im[b + 8];
+      const double x0 = __builtin_fma(-ci, g[8 * b + 3], __builtin_fma(cr, g[8 * b + 2],
+                            __builtin_fma(-ai, g[8 * b + 1], ar * g[8 * b + 0])));
+      const double x1 = __builtin_fma(ci, g[8 * b + 7], __builtin_fma(-cr, g[8 * b + 6],
+                            __builtin_fma(-ai, g[8 * b + 5], ar * g[8 * b + 4])));
+      lo(std::integral_constant<int, b>{}, x0);
+      lo(std::integral_constant<int, b + 8>{}, x1);
+    });
+  });
 }
 
 // Software-pipelined pass over [0, 16) in groups of G (see wfft::Pipe32).
@@ -320,6 +373,67 @@ __device__ __forceinline__ void inv_dft4_with_t2(double (&re)[16], double (&im)[
   });
 }
 
+// ---- steps 2 + 4 (forward) and 2 + 7 (inverse): T1 inside the radix-2 stage that follows it ----
+// A butterfly whose two inputs both carry a twiddle, a' = wa a + wb b, b' = wa a - wb b, in ten
+// instructions (p = wa a: 4, a' = p + wb b: 4, b' = 2 p - a': 2) instead of two complex products and
+// four additions (12), in place.  CONJ multiplies by the conjugates.
+#ifndef WFFT64_FUSED_T1
+#define WFFT64_FUSED_T1 1
+#endif
+template <bool CONJ>
+__device__ __forceinline__ void butterfly_ww(double& ar, double& ai, double& br, double& bi, const cplx& wa,
+                                             const cplx& wb) {
+  double t0, t1;
+  if constexpr (!CONJ)
+    asm("v_mul_f64 %4, %1, %7\n\tv_mul_f64 %5, %1, %6\n\t"
+        "v_fma_f64 %4, %0, %6, -%4\n\tv_fma_f64 %5, %0, %7, %5\n\t"
+        "v_fma_f64 %0, -%3, %9, %4\n\tv_fma_f64 %1, %3, %8, %5\n\t"
+        "v_fma_f64 %0, %2, %8, %0\n\tv_fma_f64 %1, %2, %9, %1\n\t"
+        "v_fma_f64 %2, 2.0, %4, -%0\n\tv_fma_f64 %3, 2.0, %5, -%1"
+        : "+v"(ar), "+v"(ai), "+v"(br), "+v"(bi), "=&v"(t0), "=&v"(t1)
+        : "v"(wa.x), "v"(wa.y), "v"(wb.x), "v"(wb.y));
+  else
+    asm("v_mul_f64 %4, %1, %7\n\tv_mul_f64 %5, %1, %6\n\t"
+        "v_fma_f64 %4, %0, %6, %4\n\tv_fma_f64 %5, -%0, %7, %5\n\t"
+        "v_fma_f64 %0, %3, %9, %4\n\tv_fma_f64 %1, %3, %8, %5\n\t"
+        "v_fma_f64 %0, %2, %8, %0\n\tv_fma_f64 %1, -%2, %9, %1\n\t"
+        "v_fma_f64 %2, 2.0, %4, -%0\n\tv_fma_f64 %3, 2.0, %5, -%1"
+        : "+v"(ar), "+v"(ai), "+v"(br), "+v"(bi), "=&v"(t0), "=&v"(t1)
+        : "v"(wa.x), "v"(wa.y), "v"(wb.x), "v"(wb.y));
+}
+// The same butterfly (not conjugated) with a and b left alone and the results in registers of
+// their own: na = wa a + wb b, nb = wa a - wb b.
+__device__ __forceinline__ void butterfly_ww_to(double ar, double ai, double br, double bi, const cplx& wa,
+                                                const cplx& wb, double& nar, double& nai, double& nbr, double& nbi) {
+  asm("v_mul_f64 %2, %5, %9\n\tv_mul_f64 %3, %5, %8\n\t"
+      "v_fma_f64 %2, %4, %8, -%2\n\tv_fma_f64 %3, %4, %9, %3\n\t"
+      "v_fma_f64 %0, -%7, %11, %2\n\tv_fma_f64 %1, %7, %10, %3\n\t"
+      "v_fma_f64 %0, %6, %10, %0\n\tv_fma_f64 %1, %6, %11, %1\n\t"
+      "v_fma_f64 %2, 2.0, %2, -%0\n\tv_fma_f64 %3, 2.0, %3, -%1"
+      : "=&v"(nar), "=&v"(nai), "=&v"(nbr), "=&v"(nbi)
+      : "v"(ar), "v"(ai), "v"(br), "v"(bi), "v"(wa.x), "v"(wa.y), "v"(wb.x), "v"(wb.y));
+}
+// Second half of the 4-point pass over logical bits (3, 2), its first half (s, d = x0 +- x2 in the
+// registers of x0, x2; t, u = x1 +- x3 in those of x1, x3) done by butterfly_ww.
+template <bool INV>
+__device__ __forceinline__ void dft4_high_bits_second_stage(double (&re)[16], double (&im)[16]) {
+  static_for<0, 4>([&](auto jc) WFFT_INLINE {
+    constexpr int j = decltype(jc)::value;
+    constexpr int p0 = br4(j), p1 = br4(4 + j), p2 = br4(8 + j), p3 = br4(12 + j);
+    const double sr = re[p0], si = im[p0], dr = re[p2], di = im[p2];
+    const double tr = re[p1], ti = im[p1], ur = re[p3], ui = im[p3];
+    re[p0] = sr + tr; im[p0] = si + ti;
+    re[p2] = sr - tr; im[p2] = si - ti;
+    if constexpr (!INV) {                                          // X1 = d - i u, X3 = d + i u
+      re[p1] = dr + ui; im[p1] = di - ur;
+      re[p3] = dr - ui; im[p3] = di + ur;
+    } else {
+      re[p1] = dr - ui; im[p1] = di + ur;
+      re[p3] = dr + ui; im[p3] = di - ur;
+    }
+  });
+}
+
 // ---- step 6: 16 x 16 transpose inside every row of 16 lanes ----------------------------------
 // Row R = lane >> 4 owns 16 tile rows of kRowStride bytes; lane (R, x) stores the f64 of its
 // register with index i at [R][i][x] and then loads row [R][x][0..15].  The padding of 16 bytes
@@ -392,6 +506,12 @@ struct Tables {
 template <int TWG = WFFT64_TW_GROUP>
 __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[16], double (&im)[16], char* tile,
                                                      const Tables& tb, int lane) {
+#if WFFT64_FUSED_TWIST
+  fwd16_first_stage_twisted_real(re, im);
+  dit_stage<2, false, true>(re, im);
+  dit_stage<4, false, true>(re, im);
+  dit_stage<8, false, true>(re, im);
+#else
   static_for<0, 4>([&](auto gc) WFFT_INLINE {
     wfft::const_seg_ptr g = w64_ptr();
     static_for<0, 4>([&](auto ic) WFFT_INLINE {
@@ -402,6 +522,28 @@ __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[16], double (&
     });
   });
   fwd16(re, im);
+#endif
+#if WFFT64_FUSED_T1
+  // T1 after the exchange, inside the first half of the 4-point pass: the element now in lane
+  // (a | ql), logical register y came from lane (y3 y2 | ql), logical register (a1 a0 y1 y0) = kr.
+  // Registers 2 m and 2 m + 1 hold the logical pair (y, y | 8), i.e. (x0, x2) or (x1, x3).
+  exchange_lane_bits(re, im, tile, lane);
+  wave_lds_fence();
+  {
+    Pipe16<TWG, 1, cplx> pipe;
+    const cplx* t1x = tb.t1 + ((lane >> 4) << 8) + (lane & 15);
+    auto load = [&](auto ic) WFFT_INLINE {
+      constexpr int y = br4(decltype(ic)::value);
+      return t1x[(y & 3) * 64 + (y >> 2) * 16];
+    };
+    pipe.prologue(load);
+    pipe.run2(load, [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
+      constexpr int p0 = decltype(i0)::value, p1 = decltype(i1)::value;
+      butterfly_ww<false>(re[p0], im[p0], re[p1], im[p1], w0, w1);
+    });
+  }
+  dft4_high_bits_second_stage<false>(re, im);
+#else
   wave_lds_fence();
   {
     Pipe16<TWG, 1, cplx> pipe;
@@ -418,6 +560,7 @@ __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[16], double (&
   }
   exchange_lane_bits(re, im, tile, lane);
   dft4_high_bits<false>(re, im);
+#endif
   const TileAddr ta = tile_addr(tile, lane);
   {
     // T2 = w64^(ql c) on the registers (c, j), c = 1..3; the real parts leave for the tile at once
@@ -445,10 +588,16 @@ __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[16], double (&
 
 // Spectrum C (spectrum layout) -> lo(integral_constant<r>, 1024 c[t]) and, when HI,
 // hi(integral_constant<r>, 1024 c[t + 1024]) for t = lane + 64 r.
-template <bool HI, int TWG = WFFT64_TW_GROUP, class Lo, class Hi>
+// STAGE1_DONE: the caller has run the first radix-2 stage of the first 16-point pass (registers
+// 2 m, 2 m + 1 hold C[2 m] +- C[2 m + 1]), as butterfly_ww does together with a pointwise product
+// C = D K (spectrum_product_stage1).
+template <bool HI, int TWG = WFFT64_TW_GROUP, bool STAGE1_DONE = false, class Lo, class Hi>
 __device__ __forceinline__ void inv1024_twisted_real(double (&re)[16], double (&im)[16], char* tile,
                                                      const Tables& tb, int lane, Lo&& lo, Hi&& hi) {
-  inv16(re, im);
+  if constexpr (!STAGE1_DONE) dit_stage<1, true, false>(re, im);
+  dit_stage<2, true, false>(re, im);
+  dit_stage<4, true, false>(re, im);
+  dit_stage<8, true, false>(re, im);
   const TileAddr ta = tile_addr(tile, lane);
   row_transpose<false, true>(re, ta);
   row_transpose<false, true>(im, ta);
@@ -483,23 +632,41 @@ __device__ __forceinline__ void inv1024_twisted_real(double (&re)[16], double (&
     auto load = [&](auto ic) WFFT_INLINE { return tb.t1[br4(decltype(ic)::value) * 64 + lane]; };
 #endif
     pipe.prologue(load);
+#if WFFT64_FUSED_T1
+    // conj(T1) inside the first stage of the 16-point pass, whose butterflies pair registers 2 m, 2 m + 1
+    pipe.run2(load, [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
+      constexpr int p0 = decltype(i0)::value, p1 = decltype(i1)::value;
+      butterfly_ww<true>(re[p0], im[p0], re[p1], im[p1], w0, w1);
+    });
+  }
+  dit_stage<2, true, false>(re, im);
+  dit_stage<4, true, false>(re, im);
+  constexpr bool kLastStageUntwists = WFFT64_FUSED_TWIST && !HI;
+  if constexpr (!kLastStageUntwists) dit_stage<8, true, false>(re, im);
+#else
     pipe.run2(load, [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
       constexpr int p0 = decltype(i0)::value, p1 = decltype(i1)::value;
       wfft::cmul2<true>(re[p0], im[p0], w0, re[p1], im[p1], w1);
     });
   }
   inv16(re, im);
-  static_for<0, 4>([&](auto gc) WFFT_INLINE {
-    wfft::const_seg_ptr g = w64_ptr();
-    static_for<0, 4>([&](auto ic) WFFT_INLINE {
-      constexpr int r = decltype(gc)::value * 4 + decltype(ic)::value;
-      const std::integral_constant<int, r> rc;
-      const double c = g[2 * r], s = g[2 * r + 1];
-      const double l = re[r] * c + im[r] * s;          // y conj(w64^r)
-      if constexpr (HI) hi(rc, re[r] * s - im[r] * c);
-      lo(rc, l);
+  constexpr bool kLastStageUntwists = false;
+#endif
+  if constexpr (kLastStageUntwists) {
+    inv16_last_stage_untwisted_real(re, im, lo);
+  } else {
+    static_for<0, 4>([&](auto gc) WFFT_INLINE {
+      wfft::const_seg_ptr g = w64_ptr();
+      static_for<0, 4>([&](auto ic) WFFT_INLINE {
+        constexpr int r = decltype(gc)::value * 4 + decltype(ic)::value;
+        const std::integral_constant<int, r> rc;
+        const double c = g[2 * r], s = g[2 * r + 1];
+        const double l = re[r] * c + im[r] * s;          // y conj(w64^r)
+        if constexpr (HI) hi(rc, re[r] * s - im[r] * c);
+        lo(rc, l);
+      });
     });
-  });
+  }
 }
 
 }  // namespace wfft64
