@@ -1136,7 +1136,7 @@ __global__ __launch_bounds__(64 * 4 * L) void blind_rotate_split64_kernel(BlindR
     wfft64::Pipe16<4, TFHE_SPLIT_KEY_DEPTH, cplx> kp;
     kp.prologue(load_k);
     __builtin_amdgcn_sched_barrier(0);
-    wfft64::fwd1024_twisted_real(re, im, tile, tb, lane);
+    wfft64::fwd1024_twisted_real<WFFT64_TW_GROUP, false>(re, im, tile, tb, lane);
     kp.run2(load_k, [&](auto i0, const cplx& k0, auto i1, const cplx& k1) WFFT_INLINE {
       constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;
 #if TFHE_PRODUCT_STAGE1
@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(64 * 4 * L) void blind_rotate_split64_kernel(BlindR
       wfft::cmul2<false>(re[s0], im[s0], k0, re[s1], im[s1], k1);
 #endif
     });
-    wfft64::inv1024_twisted_real<false, WFFT64_TW_GROUP, TFHE_PRODUCT_STAGE1 != 0>(
+    wfft64::inv1024_twisted_real<false, WFFT64_TW_GROUP, TFHE_PRODUCT_STAGE1 != 0, false>(
         re, im, tile, tb, lane,
         [&](auto rc, double v) WFFT_INLINE {
           constexpr int r = decltype(rc)::value;
@@ -1324,7 +1324,7 @@ __global__ __launch_bounds__(64 * kWaves64) void blind_rotate_textbook_kernel(Bl
             constexpr int r = decltype(rc)::value;
             re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(tt.template get<j, r>(), decal, BGBIT);
           });
-          wfft64::fwd1024_twisted_real(re, im, tile, tb, lane);
+          wfft64::fwd1024_twisted_real<WFFT64_TW_GROUP, false>(re, im, tile, tb, lane);
           const cplx* krow = bk_i + (size_t)(2 * p + j) * 2 * 1024;
           static_for<0, 2>([&](auto uc) WFFT_INLINE {
             constexpr int u = decltype(uc)::value;
@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(64 * kWaves64) void blind_rotate_textbook_kernel(Bl
       static_for<0, 2>([&](auto uc) WFFT_INLINE {
         constexpr int u = decltype(uc)::value;
         double lo_v[16];
-        wfft64::inv1024_twisted_real<true>(
+        wfft64::inv1024_twisted_real<true, WFFT64_TW_GROUP, false, false>(
             ur[u], ui[u], tile, tb, lane, [&](auto rc, double v) WFFT_INLINE { lo_v[decltype(rc)::value] = v; },
             [&](auto rc, double v) WFFT_INLINE { ui[u][decltype(rc)::value] = v; });
         // negacyclic product = low half - high half of the convolution; acc[u] += it, modulo 2^32

@@ -137,9 +137,6 @@ __device__ __forceinline__ void inv16(double (&re)[16], double (&im)[16]) {
 // (whose butterflies pair registers r and r + 8, without twiddles): for REAL inputs x = re[r],
 // y = re[r + 8] the outputs x w64^r +- y w64^(r+8) cost six instructions per butterfly instead of
 // four products and four additions.
-#ifndef WFFT64_FUSED_TWIST
-#define WFFT64_FUSED_TWIST 1
-#endif
 __device__ __forceinline__ void fwd16_first_stage_twisted_real(double (&re)[16], double (&im)[16]) {
   static_for<0, 4>([&](auto gc) WFFT_INLINE {
     wfft::const_seg_ptr g = w64_ptr();
@@ -346,9 +343,6 @@ __device__ __forceinline__ void dit_butterfly2_v(double a0r, double a0i, double&
       : "=&v"(n0r), "=&v"(n0i), "=&v"(n1r), "=&v"(n1i), "+v"(b0r), "+v"(b0i), "+v"(b1r), "+v"(b1i)
       : "v"(a0r), "v"(a0i), "v"(a1r), "v"(a1i), "v"(vr0), "v"(vi0), "v"(vr1), "v"(vi1));
 }
-#ifndef WFFT64_FUSED_T2
-#define WFFT64_FUSED_T2 1
-#endif
 // w1 = w64^ql, w2 = w64^(2 ql) as stored in T2 (not conjugated)
 __device__ __forceinline__ void inv_dft4_with_t2(double (&re)[16], double (&im)[16], const cplx& w1, const cplx& w2) {
   const double m1i = -w1.y, m2i = -w2.y;                        // conj(w) = (w.x, -w.y)
@@ -503,33 +497,23 @@ struct Tables {
 // ---- the twisted transforms of a REAL polynomial (see wave_fft.hpp for the mathematics) ------
 // x[lane + 64 r] in re[r] -> spectrum layout.  The register part w64^r of the twist w4096^n comes
 // from the constant segment (scalar loads), the lane part w4096^lane is folded into T1.
-template <int TWG = WFFT64_TW_GROUP>
+// FUSE: T1 inside the radix-2 stage next to it (butterfly_ww) and, in the inverse transform, the
+// untwist inside the last stage; fewer instructions, longer dependency chains and a few more live
+// registers: it pays in the throughput kernels (+2.6 % gates/s on MI355X), not in the kernel that
+// runs one ciphertext per workgroup (latency) nor in the textbook kernel (registers).
+template <int TWG = WFFT64_TW_GROUP, bool FUSE = (WFFT64_FUSED_T1 != 0)>
 __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[16], double (&im)[16], char* tile,
                                                      const Tables& tb, int lane) {
-#if WFFT64_FUSED_TWIST
   fwd16_first_stage_twisted_real(re, im);
   dit_stage<2, false, true>(re, im);
   dit_stage<4, false, true>(re, im);
   dit_stage<8, false, true>(re, im);
-#else
-  static_for<0, 4>([&](auto gc) WFFT_INLINE {
-    wfft::const_seg_ptr g = w64_ptr();
-    static_for<0, 4>([&](auto ic) WFFT_INLINE {
-      constexpr int r = decltype(gc)::value * 4 + decltype(ic)::value;
-      const double c = g[2 * r], s = g[2 * r + 1];
-      im[r] = re[r] * s;
-      re[r] = re[r] * c;
-    });
-  });
-  fwd16(re, im);
-#endif
-#if WFFT64_FUSED_T1
-  // T1 after the exchange, inside the first half of the 4-point pass: the element now in lane
-  // (a | ql), logical register y came from lane (y3 y2 | ql), logical register (a1 a0 y1 y0) = kr.
-  // Registers 2 m and 2 m + 1 hold the logical pair (y, y | 8), i.e. (x0, x2) or (x1, x3).
-  exchange_lane_bits(re, im, tile, lane);
-  wave_lds_fence();
-  {
+  if constexpr (FUSE) {
+    // T1 after the exchange, inside the first half of the 4-point pass: the element now in lane
+    // (a | ql), logical register y came from lane (y3 y2 | ql), logical register (a1 a0 y1 y0) = kr.
+    // Registers 2 m and 2 m + 1 hold the logical pair (y, y | 8), i.e. (x0, x2) or (x1, x3).
+    exchange_lane_bits(re, im, tile, lane);
+    wave_lds_fence();
     Pipe16<TWG, 1, cplx> pipe;
     const cplx* t1x = tb.t1 + ((lane >> 4) << 8) + (lane & 15);
     auto load = [&](auto ic) WFFT_INLINE {
@@ -541,11 +525,9 @@ __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[16], double (&
       constexpr int p0 = decltype(i0)::value, p1 = decltype(i1)::value;
       butterfly_ww<false>(re[p0], im[p0], re[p1], im[p1], w0, w1);
     });
-  }
-  dft4_high_bits_second_stage<false>(re, im);
-#else
-  wave_lds_fence();
-  {
+    dft4_high_bits_second_stage<false>(re, im);
+  } else {
+    wave_lds_fence();
     Pipe16<TWG, 1, cplx> pipe;
 #ifdef WFFT64_ABLATE_T1
     auto load = [&](auto ic) WFFT_INLINE { return cplx{0.75 + decltype(ic)::value, 0.5}; };
@@ -557,10 +539,9 @@ __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[16], double (&
       constexpr int p0 = decltype(i0)::value, p1 = decltype(i1)::value;      // physical: kr = br4(p)
       wfft::cmul2<false>(re[p0], im[p0], w0, re[p1], im[p1], w1);
     });
+    exchange_lane_bits(re, im, tile, lane);
+    dft4_high_bits<false>(re, im);
   }
-  exchange_lane_bits(re, im, tile, lane);
-  dft4_high_bits<false>(re, im);
-#endif
   const TileAddr ta = tile_addr(tile, lane);
   {
     // T2 = w64^(ql c) on the registers (c, j), c = 1..3; the real parts leave for the tile at once
@@ -590,8 +571,9 @@ __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[16], double (&
 // hi(integral_constant<r>, 1024 c[t + 1024]) for t = lane + 64 r.
 // STAGE1_DONE: the caller has run the first radix-2 stage of the first 16-point pass (registers
 // 2 m, 2 m + 1 hold C[2 m] +- C[2 m + 1]), as butterfly_ww does together with a pointwise product
-// C = D K (spectrum_product_stage1).
-template <bool HI, int TWG = WFFT64_TW_GROUP, bool STAGE1_DONE = false, class Lo, class Hi>
+// C = D K.  FUSE as in the forward transform.
+template <bool HI, int TWG = WFFT64_TW_GROUP, bool STAGE1_DONE = false, bool FUSE = (WFFT64_FUSED_T1 != 0), class Lo,
+          class Hi>
 __device__ __forceinline__ void inv1024_twisted_real(double (&re)[16], double (&im)[16], char* tile,
                                                      const Tables& tb, int lane, Lo&& lo, Hi&& hi) {
   if constexpr (!STAGE1_DONE) dit_stage<1, true, false>(re, im);
@@ -601,29 +583,14 @@ __device__ __forceinline__ void inv1024_twisted_real(double (&re)[16], double (&
   const TileAddr ta = tile_addr(tile, lane);
   row_transpose<false, true>(re, ta);
   row_transpose<false, true>(im, ta);
-#if WFFT64_FUSED_T2
   {
     const cplx* t2 = tb.t2 + (lane & 15);
     const cplx w1 = t2[0], w2 = t2[16];
     inv_dft4_with_t2(re, im, w1, w2);
   }
-#else
-  {
-    const cplx* t2 = tb.t2 + (lane & 15);
-    const cplx w1 = t2[0], w2 = t2[16], w3 = t2[32];
-    const cplx* wc[3] = {&w1, &w2, &w3};
-    static_for<1, 4>([&](auto cc) WFFT_INLINE {
-      constexpr int c = decltype(cc)::value;
-      static_for<0, 2>([&](auto hc) WFFT_INLINE {
-        constexpr int x0 = 4 * c + 2 * decltype(hc)::value, x1 = x0 + 1;
-        wfft::cmul2<true>(re[br4(x0)], im[br4(x0)], *wc[c - 1], re[br4(x1)], im[br4(x1)], *wc[c - 1]);
-      });
-    });
-  }
-  dft4_high_bits<true>(re, im);
-#endif
   exchange_lane_bits(re, im, tile, lane);
   wave_lds_fence();
+  constexpr bool kLastStageUntwists = FUSE && !HI;
   {
     Pipe16<TWG, 1, cplx> pipe;
 #ifdef WFFT64_ABLATE_T1
@@ -632,29 +599,20 @@ __device__ __forceinline__ void inv1024_twisted_real(double (&re)[16], double (&
     auto load = [&](auto ic) WFFT_INLINE { return tb.t1[br4(decltype(ic)::value) * 64 + lane]; };
 #endif
     pipe.prologue(load);
-#if WFFT64_FUSED_T1
-    // conj(T1) inside the first stage of the 16-point pass, whose butterflies pair registers 2 m, 2 m + 1
+    // conj(T1), then the 16-point pass whose first stage pairs registers 2 m, 2 m + 1
     pipe.run2(load, [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
       constexpr int p0 = decltype(i0)::value, p1 = decltype(i1)::value;
-      butterfly_ww<true>(re[p0], im[p0], re[p1], im[p1], w0, w1);
+      if constexpr (FUSE) butterfly_ww<true>(re[p0], im[p0], re[p1], im[p1], w0, w1);
+      else wfft::cmul2<true>(re[p0], im[p0], w0, re[p1], im[p1], w1);
     });
   }
+  if constexpr (!FUSE) dit_stage<1, true, false>(re, im);
   dit_stage<2, true, false>(re, im);
   dit_stage<4, true, false>(re, im);
-  constexpr bool kLastStageUntwists = WFFT64_FUSED_TWIST && !HI;
-  if constexpr (!kLastStageUntwists) dit_stage<8, true, false>(re, im);
-#else
-    pipe.run2(load, [&](auto i0, const cplx& w0, auto i1, const cplx& w1) WFFT_INLINE {
-      constexpr int p0 = decltype(i0)::value, p1 = decltype(i1)::value;
-      wfft::cmul2<true>(re[p0], im[p0], w0, re[p1], im[p1], w1);
-    });
-  }
-  inv16(re, im);
-  constexpr bool kLastStageUntwists = false;
-#endif
   if constexpr (kLastStageUntwists) {
     inv16_last_stage_untwisted_real(re, im, lo);
   } else {
+    dit_stage<8, true, false>(re, im);
     static_for<0, 4>([&](auto gc) WFFT_INLINE {
       wfft::const_seg_ptr g = w64_ptr();
       static_for<0, 4>([&](auto ic) WFFT_INLINE {
