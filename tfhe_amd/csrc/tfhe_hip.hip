@@ -1050,13 +1050,17 @@ __global__ __launch_bounds__(64 * kWaves64) void blind_rotate64_kernel(BlindRota
 // ---------------------------------------------------------------------------
 // Low-latency mapping on the transforms of wave_fft64.hpp: one workgroup per ciphertext, one
 // WAVEFRONT per (digit polynomial, key polynomial) product of tgsw_extern_mul_to_tlwe
-// (src/tgsw.rs:229-264): wavefront ((p 2 + h) 2 + u) decomposes accumulator polynomial h at level p,
-// transforms the digits, multiplies by K_{h,u} and, after the inverse transform, adds its rounded
-// product into the shared accumulator in LDS (ds_add_u32; each product rounded on its own).
-// 4 l wavefronts, i.e. l per SIMD, whose round trips overlap; an iteration costs the latency of one
-// forward and one inverse transform (each forward transform is computed twice).  The accumulator,
-// the previous accumulator and the sample being decomposed are shared in LDS ([2][N] int32 each,
-// the sample XORed with tt_mask); two workgroup barriers per iteration order the rotation.
+// (src/tgsw.rs:229-264): wavefront u 2 l + (2 p + h) multiplies the spectrum D of the level-p digits
+// of accumulator polynomial h by K_{h,u} and, after the inverse transform, adds its rounded product
+// into the shared accumulator in LDS (ds_add_u32; each product rounded on its own).  The two
+// wavefronts of a pair (p, h) need the same D: the one with u = 0 decomposes and transforms (numbered
+// so that these 2 l wavefronts spread over all SIMDs and run the forward transform with a SIMD to
+// themselves) and hands D to its partner through LDS, in the two wavefronts' exchange tiles, which
+// are idle between a forward transform's last and an inverse transform's first transposition.
+// An iteration costs the latency of one forward and one inverse transform.  The accumulator, the
+// previous accumulator and the sample being decomposed are shared in LDS ([2][N] int32 each, the
+// sample XORed with tt_mask).  Four workgroup barriers per iteration: accumulator complete, sample
+// complete, spectra handed over, spectra consumed (the tiles may be written again).
 // ---------------------------------------------------------------------------
 template <int L>
 constexpr int split64_lds_bytes() {
@@ -1074,8 +1078,14 @@ __global__ __launch_bounds__(64 * 4 * L) void blind_rotate_split64_kernel(BlindR
   const wfft64::Tables tb = load_tables64(shared + 3 * 2 * kN * 4, args.tables64);
   const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int p = wave >> 2, h = (wave >> 1) & 1, u = wave & 1;
+  const int pair = wave % (2 * L), u = wave / (2 * L), p = pair >> 1, h = pair & 1;
   char* tile = lds + wave * wfft64::kTileBytes;
+  // where a pair's spectrum changes hands: values 0..8 of a lane in the tile of the wavefront that
+  // computes it, 9..15 in its partner's; [value][re | im][lane] f64
+  constexpr int kInFirstTile = wfft64::kTileBytes / 1024;
+  static_assert(kInFirstTile * 1024 == wfft64::kTileBytes && 16 - kInFirstTile <= kInFirstTile, "spectrum in two tiles");
+  char* xchg0 = lds + pair * wfft64::kTileBytes;
+  char* xchg1 = lds + (pair + 2 * L) * wfft64::kTileBytes;
   const int b = blockIdx.x;
   constexpr uint32_t kMaskTt = tt_mask<L, BGBIT>();
   const int decal = 32 - (p + 1) * BGBIT;
@@ -1122,10 +1132,6 @@ __global__ __launch_bounds__(64 * 4 * L) void blind_rotate_split64_kernel(BlindR
       });
     }
     double re[16], im[16];
-    static_for<0, 16>([&](auto rc) WFFT_INLINE {
-      constexpr int r = decltype(rc)::value;
-      re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(ttL[h * kN + lane + 64 * r], decal, BGBIT);
-    });
     // K_{h,u}: block 0 of the level holds K_{h,h}, block 1 K_{h,1-h}, in the lane layout that
     // level_product64 explains; the first loads go out before the forward transform (a single
     // ciphertext's key comes from HBM, not from L2)
@@ -1136,7 +1142,28 @@ __global__ __launch_bounds__(64 * 4 * L) void blind_rotate_split64_kernel(BlindR
     wfft64::Pipe16<4, TFHE_SPLIT_KEY_DEPTH, cplx> kp;
     kp.prologue(load_k);
     __builtin_amdgcn_sched_barrier(0);
-    wfft64::fwd1024_twisted_real<WFFT64_TW_GROUP, false>(re, im, tile, tb, lane);
+    if (u == 0) {
+      static_for<0, 16>([&](auto rc) WFFT_INLINE {
+        constexpr int r = decltype(rc)::value;
+        re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(ttL[h * kN + lane + 64 * r], decal, BGBIT);
+      });
+      wfft64::fwd1024_twisted_real<WFFT64_TW_GROUP, false>(re, im, tile, tb, lane);
+      static_for<0, 16>([&](auto sc) WFFT_INLINE {
+        constexpr int v = decltype(sc)::value;
+        char* at = (v < kInFirstTile ? xchg0 + v * 1024 : xchg1 + (v - kInFirstTile) * 1024) + lane * 8;
+        *reinterpret_cast<double*>(at) = re[v];
+        *reinterpret_cast<double*>(at + 512) = im[v];
+      });
+    }
+    __syncthreads();                                           // the spectra are in LDS
+    if (u != 0) {
+      static_for<0, 16>([&](auto sc) WFFT_INLINE {
+        constexpr int v = decltype(sc)::value;
+        const char* at = (v < kInFirstTile ? xchg0 + v * 1024 : xchg1 + (v - kInFirstTile) * 1024) + lane * 8;
+        re[v] = *reinterpret_cast<const double*>(at);
+        im[v] = *reinterpret_cast<const double*>(at + 512);
+      });
+    }
     kp.run2(load_k, [&](auto i0, const cplx& k0, auto i1, const cplx& k1) WFFT_INLINE {
       constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;
 #if TFHE_PRODUCT_STAGE1
@@ -1145,6 +1172,7 @@ __global__ __launch_bounds__(64 * 4 * L) void blind_rotate_split64_kernel(BlindR
       wfft::cmul2<false>(re[s0], im[s0], k0, re[s1], im[s1], k1);
 #endif
     });
+    __syncthreads();                                           // the spectra have been read: the tiles are free
     wfft64::inv1024_twisted_real<false, WFFT64_TW_GROUP, TFHE_PRODUCT_STAGE1 != 0, false>(
         re, im, tile, tb, lane,
         [&](auto rc, double v) WFFT_INLINE {
