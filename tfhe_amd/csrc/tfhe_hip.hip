@@ -1147,7 +1147,7 @@ __global__ __launch_bounds__(64 * 4 * L) void blind_rotate_split64_kernel(BlindR
         constexpr int r = decltype(rc)::value;
         re[r] = (double)(int32_t)__builtin_amdgcn_sbfe(ttL[h * kN + lane + 64 * r], decal, BGBIT);
       });
-      wfft64::fwd1024_twisted_real<WFFT64_TW_GROUP, false>(re, im, tile, tb, lane);
+      wfft64::fwd1024_twisted_real(re, im, tile, tb, lane);
       static_for<0, 16>([&](auto sc) WFFT_INLINE {
         constexpr int v = decltype(sc)::value;
         char* at = (v < kInFirstTile ? xchg0 + v * 1024 : xchg1 + (v - kInFirstTile) * 1024) + lane * 8;
@@ -1173,7 +1173,7 @@ __global__ __launch_bounds__(64 * 4 * L) void blind_rotate_split64_kernel(BlindR
 #endif
     });
     __syncthreads();                                           // the spectra have been read: the tiles are free
-    wfft64::inv1024_twisted_real<false, WFFT64_TW_GROUP, TFHE_PRODUCT_STAGE1 != 0, false>(
+    wfft64::inv1024_twisted_real<false, WFFT64_TW_GROUP, TFHE_PRODUCT_STAGE1 != 0>(
         re, im, tile, tb, lane,
         [&](auto rc, double v) WFFT_INLINE {
           constexpr int r = decltype(rc)::value;

@@ -499,8 +499,8 @@ struct Tables {
 // from the constant segment (scalar loads), the lane part w4096^lane is folded into T1.
 // FUSE: T1 inside the radix-2 stage next to it (butterfly_ww) and, in the inverse transform, the
 // untwist inside the last stage; fewer instructions, longer dependency chains and a few more live
-// registers: it pays in the throughput kernels (+2.6 % gates/s on MI355X), not in the kernel that
-// runs one ciphertext per workgroup (latency) nor in the textbook kernel (registers).
+// registers: it pays in the throughput kernels (+2.6 % gates/s on MI355X) and in the kernel that
+// runs one ciphertext per workgroup (-2.5 % latency), not in the textbook kernel (registers).
 template <int TWG = WFFT64_TW_GROUP, bool FUSE = (WFFT64_FUSED_T1 != 0)>
 __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[16], double (&im)[16], char* tile,
                                                      const Tables& tb, int lane) {
