@@ -125,7 +125,8 @@ int tfhe_hip_synchronize(tfhe_hip_ctx* ctx);
  *          Both are throughput forms with persistent workgroups.
  * SPLIT:   one ciphertext per workgroup, one wavefront per (digit polynomial, key
  *          polynomial) product of tgsw_extern_mul_to_tlwe (src/tgsw.rs:229-264): 4 l
- *          wavefronts; under a third of the latency, twice the forward transforms.
+ *          wavefronts, the two that share a digit polynomial's spectrum pass it through
+ *          LDS; under a third of the latency.
  * AUTO (default): whole rounds of BATCH64 (one ciphertext per wavefront slot, the
  *          fastest throughput form on MI355X for both parameter sets) and, for what is
  *          left over, the cheapest of one more BATCH64 round, one BATCH round, SPLIT
