@@ -26,7 +26,7 @@
 #include "wave_fft.hpp"
 
 // Timing experiments (never the shipped build): WFFT64_ABLATE_SWAP, WFFT64_ABLATE_TRANSPOSE and
-// WFFT64_ABLATE_T1 here, TFHE_ABLATE_KEY and TFHE_ABLATE_PM_STORE in the kernel unit, each compile
+// WFFT64_ABLATE_T1 (with -DWFFT64_FUSED_T1=0) here, TFHE_ABLATE_KEY and TFHE_ABLATE_PM_STORE in the kernel unit, each compile
 // one kind of data movement out; the results are wrong by construction, only the launch time is
 // of interest (tools/sweep_variants.py builds such variants side by side).
 namespace wfft64 {
