@@ -1059,12 +1059,23 @@ __global__ __launch_bounds__(64 * kWaves64) void blind_rotate64_kernel(BlindRota
 // are idle between a forward transform's last and an inverse transform's first transposition.
 // An iteration costs the latency of one forward and one inverse transform.  The accumulator, the
 // previous accumulator and the sample being decomposed are shared in LDS ([2][N] int32 each, the
-// sample XORed with tt_mask).  Four workgroup barriers per iteration: accumulator complete, sample
-// complete, spectra handed over, spectra consumed (the tiles may be written again).
+// sample XORed with tt_mask).  Two workgroup barriers per iteration (accumulator complete, sample
+// complete); the handover is ordered inside a pair by two counters in LDS, "spectrum written" and
+// "spectrum read" (the wavefront that computed it waits for the latter before its inverse transform
+// writes to its tile again; by then its partner has long read, so neither wait costs a workgroup
+// barrier's alignment of all wavefronts: 6 - 8 % of a gate's latency).
 // ---------------------------------------------------------------------------
 template <int L>
 constexpr int split64_lds_bytes() {
-  return 4 * L * wfft64::kTileBytes + 3 * 2 * kN * 4 + wfft64::kTableBytes;
+  return 4 * L * wfft64::kTileBytes + 3 * 2 * kN * 4 + wfft64::kTableBytes + 2 * 2 * L * 4;
+}
+// counters in LDS between the wavefronts of a pair; a wavefront's LDS operations are served in
+// program order, so a counter written after the data (or after the reads) is seen after them
+__device__ __forceinline__ void lds_counter_set(int* c, int v) {
+  __hip_atomic_store(c, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_counter_wait(int* c, int v) {
+  while (__hip_atomic_load(c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != v) __builtin_amdgcn_s_sleep(1);
 }
 
 template <int L, int BGBIT, bool HOOK>
@@ -1075,10 +1086,15 @@ __global__ __launch_bounds__(64 * 4 * L) void blind_rotate_split64_kernel(BlindR
   int32_t* prevL = reinterpret_cast<int32_t*>(shared);
   int32_t* accL = prevL + 2 * kN;
   int32_t* ttL = accL + 2 * kN;
+  int* counters = reinterpret_cast<int*>(shared + 3 * 2 * kN * 4 + wfft64::kTableBytes);
+  if (threadIdx.x < 2 * 2 * L) counters[threadIdx.x] = 0;       // before the barrier in load_tables64
   const wfft64::Tables tb = load_tables64(shared + 3 * 2 * kN * 4, args.tables64);
   const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int pair = wave % (2 * L), u = wave / (2 * L), p = pair >> 1, h = pair & 1;
+  int* written = counters + pair;                              // iterations whose spectrum is in LDS
+  int* consumed = counters + 2 * L + pair;                     // iterations whose spectrum has been read
+  int done = 0;                                                // iterations run (those with abar = 0 are skipped)
   char* tile = lds + wave * wfft64::kTileBytes;
   // where a pair's spectrum changes hands: values 0..8 of a lane in the tile of the wavefront that
   // computes it, 9..15 in its partner's; [value][re | im][lane] f64
@@ -1102,6 +1118,7 @@ __global__ __launch_bounds__(64 * 4 * L) void blind_rotate_split64_kernel(BlindR
     if ((i & 63) == 0) abar64 = (i + lane0 < args.n) ? bara[i + lane0] : 0;
     const int abar = __builtin_amdgcn_readlane(abar64, i & 63);
     if (abar == 0) continue;                                   // bootstrapping.rs:122-126
+    done++;
     __syncthreads();                                           // acc of the last iteration is complete
     int lane = lane0;
     asm volatile("" : "+v"(lane));                             // keeps per-lane addresses out of the loop's live-in set
@@ -1154,15 +1171,16 @@ __global__ __launch_bounds__(64 * 4 * L) void blind_rotate_split64_kernel(BlindR
         *reinterpret_cast<double*>(at) = re[v];
         *reinterpret_cast<double*>(at + 512) = im[v];
       });
-    }
-    __syncthreads();                                           // the spectra are in LDS
-    if (u != 0) {
+      lds_counter_set(written, done);
+    } else {
+      lds_counter_wait(written, done);
       static_for<0, 16>([&](auto sc) WFFT_INLINE {
         constexpr int v = decltype(sc)::value;
         const char* at = (v < kInFirstTile ? xchg0 + v * 1024 : xchg1 + (v - kInFirstTile) * 1024) + lane * 8;
         re[v] = *reinterpret_cast<const double*>(at);
         im[v] = *reinterpret_cast<const double*>(at + 512);
       });
+      lds_counter_set(consumed, done);
     }
     kp.run2(load_k, [&](auto i0, const cplx& k0, auto i1, const cplx& k1) WFFT_INLINE {
       constexpr int s0 = decltype(i0)::value, s1 = decltype(i1)::value;
@@ -1172,14 +1190,16 @@ __global__ __launch_bounds__(64 * 4 * L) void blind_rotate_split64_kernel(BlindR
       wfft::cmul2<false>(re[s0], im[s0], k0, re[s1], im[s1], k1);
 #endif
     });
-    __syncthreads();                                           // the spectra have been read: the tiles are free
     wfft64::inv1024_twisted_real<false, WFFT64_TW_GROUP, TFHE_PRODUCT_STAGE1 != 0>(
         re, im, tile, tb, lane,
         [&](auto rc, double v) WFFT_INLINE {
           constexpr int r = decltype(rc)::value;
           atomicAdd(reinterpret_cast<unsigned*>(accL) + u * kN + lane + 64 * r, (unsigned)wfft::round_sat_i32(v));
         },
-        [](auto, double) {});
+        [](auto, double) {},
+        [&]() WFFT_INLINE {
+          if (u == 0) lds_counter_wait(consumed, done);        // the partner has read what this tile held
+        });
   }
   __syncthreads();
 

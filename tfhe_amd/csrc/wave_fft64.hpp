@@ -572,14 +572,20 @@ __device__ __forceinline__ void fwd1024_twisted_real(double (&re)[16], double (&
 // STAGE1_DONE: the caller has run the first radix-2 stage of the first 16-point pass (registers
 // 2 m, 2 m + 1 hold C[2 m] +- C[2 m + 1]), as butterfly_ww does together with a pointwise product
 // C = D K.  FUSE as in the forward transform.
+// before_tile() runs after the first 16-point pass, before the transform first writes to its tile.
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
 template <bool HI, int TWG = WFFT64_TW_GROUP, bool STAGE1_DONE = false, bool FUSE = (WFFT64_FUSED_T1 != 0), class Lo,
-          class Hi>
+          class Hi, class BeforeTile = NoHook>
 __device__ __forceinline__ void inv1024_twisted_real(double (&re)[16], double (&im)[16], char* tile,
-                                                     const Tables& tb, int lane, Lo&& lo, Hi&& hi) {
+                                                     const Tables& tb, int lane, Lo&& lo, Hi&& hi,
+                                                     BeforeTile&& before_tile = BeforeTile{}) {
   if constexpr (!STAGE1_DONE) dit_stage<1, true, false>(re, im);
   dit_stage<2, true, false>(re, im);
   dit_stage<4, true, false>(re, im);
   dit_stage<8, true, false>(re, im);
+  before_tile();
   const TileAddr ta = tile_addr(tile, lane);
   row_transpose<false, true>(re, ta);
   row_transpose<false, true>(im, ta);
