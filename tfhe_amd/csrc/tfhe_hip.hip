@@ -81,7 +81,7 @@ struct StampCtx {
 // Low-latency kernel: the first loads of a wavefront's key block are issued before the
 // forward transform; depth of their software pipeline in groups of four.
 #ifndef TFHE_SPLIT_KEY_DEPTH
-#define TFHE_SPLIT_KEY_DEPTH 3
+#define TFHE_SPLIT_KEY_DEPTH 2
 #endif
 
 // Where the accumulator of the blind rotation lives between uses: parked in
